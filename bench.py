@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- RoIRotate forward throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one forward pass of the hot path (prologue relayout + gather kernel)
+over one batch of synthetic input already resident in HBM:  BASELINE.json
+configs[1]  -- features 1x256x160x160 fp32 (NCHW, the reference contract), 512
+random rotated ROIs, pooled 8x64, spatial_scale 0.25.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) the ROIs of a 512*N set are row-sharded
+512 per rank with no data-path collective (configs[3], weak scaling); the time is
+the max over ranks.
+
+Prints ONE JSON line on rank 0.  `value` = ROIs/s of the whole job (both kernels,
+wall clock of the timed region).  `roofline` is for the dominant kernel
+(rroi_fwd_tiled_kernel), from HIP events recorded around that launch alone in a
+second K-step loop on the same stream.  `cpu_baseline` = the oracle (a C port of
+the reference's per-element semantics; the reference has no runnable CPU path)
+timed on this host's cores -- a reported baseline, not the thing measured.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "fots.pytorch_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+CFG = dict(R=512, C=256, H=160, W=160, img=640, PH=8, PW=64, scale=0.25)
+
+
+def make_inputs(R, C=256, H=160, W=160, img=640, seed=0):
+    """features ~ N(0,1); cx,cy ~ U[0,img), h ~ U[16,64), w = h*U[4,8),
+    angle ~ U[-90,90) degrees, batch index 0."""
+    rng = np.random.default_rng(seed)
+    feats = rng.standard_normal((1, C, H, W), dtype=np.float32)
+    cx = rng.uniform(0, img, R)
+    cy = rng.uniform(0, img, R)
+    h = rng.uniform(16, 64, R)
+    w = h * rng.uniform(4, 8, R)
+    ang = rng.uniform(-90, 90, R)
+    rois = np.stack([np.zeros(R), cx, cy, h, w, ang], 1).astype(np.float32)
+    return feats, rois
+
+
+def cpu_baseline(feats, rois):
+    """Oracle timed on the host (rank 0, N = 1 only).  Imports oracle/ -- allowed here only."""
+    sys.path.insert(0, ROOT)
+    from oracle import rroi_align_oracle as O
+    c = CFG
+    cores = O.max_threads()
+    # bounded sample: the full 512-ROI workload once on 1 thread (a few s) and 3x on all cores
+    t0 = time.perf_counter()
+    O.forward_c(feats, rois[:128], c["PH"], c["PW"], c["scale"], threads=1)
+    t1 = (time.perf_counter() - t0) * 4.0  # 128 of 512 ROIs
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.forward_c(feats, rois, c["PH"], c["PW"], c["scale"], threads=cores)
+        best = min(best, time.perf_counter() - t0)
+    touched = O.touched_pixels(rois, 1, c["H"], c["W"], c["PH"], c["PW"], c["scale"])
+    return {
+        "value": round(len(rois) / best, 1), "unit": "ROIs/s", "cores": cores, "kind": "port",
+        "sample": "full workload (512 ROIs x 256 ch x 8x64), oracle/rroi_align_oracle.c hoisted "
+                  "forward, OpenMP over ROIs, best of 3; single-thread (128-ROI sample x4): "
+                  "%.1f ROIs/s" % (len(rois) / t1),
+        "ms_per_step": round(best * 1e3, 2),
+    }, touched
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from rroi_align._ext import rroi_align as ext  # fails loudly if the HIP library is missing
+    from rroi_align.sharded import shard_bounds
+
+    c = CFG
+    feats_np, rois_all = make_inputs(c["R"] * world, c["C"], c["H"], c["W"], c["img"])
+    lo, hi = shard_bounds(len(rois_all), world, rank)
+    rois_np = rois_all[lo:hi]
+    feats = torch.from_numpy(feats_np).to(dev)
+    rois = torch.from_numpy(rois_np).to(dev)
+    R = rois.shape[0]
+
+    # pre-allocated output and workspace; inputs resident in HBM before timing
+    out = torch.empty((R, c["C"], c["PH"], c["PW"]), dtype=torch.float32, device=dev)
+    nbytes = ext._lib.rroi_align_forward_workspace_bytes(1, c["C"], c["H"], c["W"], R, ext.LAYOUT_NCHW)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def launch(stages):
+        st = ext._lib.rroi_align_forward_stages_hip(
+            feats.data_ptr(), ext.LAYOUT_NCHW, c["scale"], 1, R, c["H"], c["W"], c["C"], c["PH"],
+            c["PW"], rois.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, ext.PATH_TILED, stages,
+            stream)
+        if st != 1:
+            raise RuntimeError(f"rroi_align_forward_stages_hip -> {st}")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        launch(ext.STAGE_ALL)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        launch(ext.STAGE_ALL)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # second loop: HIP events around each launch, same stream, same K
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    for e0, e1, e2 in ev:
+        e0.record()
+        launch(ext.STAGE_PROLOGUE)
+        e1.record()
+        launch(ext.STAGE_GATHER)
+        e2.record()
+    torch.cuda.synchronize()
+    pro_ms = np.array([e0.elapsed_time(e1) for e0, e1, _ in ev])
+    gat_ms = np.array([e1.elapsed_time(e2) for _, e1, e2 in ev])
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = R * world * args.steps / elapsed
+
+    cpu, touched = (None, None)
+    if world == 1 and not args.no_cpu_baseline:
+        cpu, touched = cpu_baseline(feats_np, rois_np)
+    # algorithmic bytes of one gather launch: output + rois + unique feature taps
+    bytes_out = R * c["C"] * c["PH"] * c["PW"] * 4
+    bytes_feat = (touched if touched is not None else c["H"] * c["W"]) * c["C"] * 4
+    b_alg = bytes_out + R * 24 + bytes_feat
+    gat_avg = float(gat_ms.mean())
+    achieved = b_alg / (gat_avg * 1e-3) / 1e9
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes/launch, if collected
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("rroi_fwd_tiled_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "RoIRotate forward ROIs/sec", "value": round(value, 1), "unit": "ROIs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: features 1x256x160x160 fp32 NCHW, %d rotated ROIs/GPU, "
+                               "pooled 8x64, spatial_scale 0.25, forward" % R,
+                   "rois_per_gpu": R, "rois_total": R * world, "channels": c["C"],
+                   "pooled": [c["PH"], c["PW"]], "path": "prologue(relayout+affine) + tiled gather",
+                   "parallelism": "roi-shard x%d, no data-path collective" % world},
+        "roofline": {"bound": "hbm", "kernel": "rroi_fwd_tiled_kernel", "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": traffic, "algorithmic_bytes": b_alg,
+                     "kernel_ms": {"avg": round(gat_avg, 5), "p10": round(float(np.percentile(gat_ms, 10)), 5),
+                                   "p50": round(float(np.median(gat_ms)), 5),
+                                   "p90": round(float(np.percentile(gat_ms, 90)), 5)},
+                     "prologue_ms_avg": round(float(pro_ms.mean()), 5)},
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,223 @@
+"""rroi_align._ext.rroi_align -- ctypes binding of librroi_align_hip.so.
+
+Stands where the reference's cffi extension stood (``rroi_align/build.py:7-37``
+built ``_ext.rroi_align`` from ``src/rroi_align_cuda.c``): it exports the same
+two tensor-taking functions, ``rroi_align_forward_cuda`` and
+``rroi_align_backward_cuda`` (``src/rroi_align_cuda.h:1-7``), plus the native
+entry points the autograd Function uses.
+
+The shared library is mandatory: importing this module without it raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librroi_align_hip.so")
+
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+PATH_AUTO, PATH_DIRECT, PATH_TILED = 0, 1, 2
+STAGE_PROLOGUE, STAGE_GATHER, STAGE_ALL = 1, 2, 3
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C fots.pytorch_amd/csrc` "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+        "rroi_align has no CPU or PyTorch fallback.")
+
+# torch must be imported first so that libamdhip64.so.7 resolves to the runtime
+# torch already loaded (same SONAME) and streams/pointers are interchangeable.
+_lib = ctypes.CDLL(LIB_PATH)
+
+_vp, _f, _i, _sz = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
+
+_lib.rroi_align_hip_version.restype = ctypes.c_char_p
+_lib.rroi_align_forward_workspace_bytes.restype = _sz
+_lib.rroi_align_forward_workspace_bytes.argtypes = [_i] * 6
+_lib.rroi_align_backward_workspace_bytes.restype = _sz
+_lib.rroi_align_backward_workspace_bytes.argtypes = [_i] * 5
+_lib.rroi_align_forward_hip.restype = _i
+_lib.rroi_align_forward_hip.argtypes = [_vp, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]
+_lib.rroi_align_forward_stages_hip.restype = _i
+_lib.rroi_align_forward_stages_hip.argtypes = [_vp, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _i, _vp]
+_lib.rroi_align_backward_hip.restype = _i
+_lib.rroi_align_backward_hip.argtypes = [_vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]
+_lib.rroi_align_bin_centres_hip.restype = _i
+_lib.rroi_align_bin_centres_hip.argtypes = [_f, _i, _i, _i, _i, _i, _vp, _vp, _vp]
+_lib.rroi_align_sincos_probe_hip.restype = _i
+_lib.rroi_align_sincos_probe_hip.argtypes = [_vp, _i, _vp, _vp]
+_lib.RROIAlignForwardLaucher.restype = _i
+_lib.RROIAlignForwardLaucher.argtypes = [_vp, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
+_lib.RROIAlignBackwardLaucher.restype = _i
+_lib.RROIAlignBackwardLaucher.argtypes = [_vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
+
+EXPORTS = (
+    "RROIAlignForwardLaucher", "RROIAlignBackwardLaucher", "rroi_align_forward_hip",
+    "rroi_align_backward_hip", "rroi_align_forward_stages_hip", "rroi_align_forward_workspace_bytes",
+    "rroi_align_backward_workspace_bytes", "rroi_align_bin_centres_hip",
+    "rroi_align_sincos_probe_hip", "rroi_align_hip_version",
+)
+
+
+def version() -> str:
+    return _lib.rroi_align_hip_version().decode()
+
+
+def _check(status: int, what: str) -> None:
+    if status == 1:
+        return
+    if status == 0:
+        raise ValueError(f"{what}: invalid argument (shape/layout/workspace)")
+    raise RuntimeError(f"{what}: HIP error {-status}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda_f32(t: torch.Tensor, name: str) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: rroi_align runs on the GPU only (the reference's CPU "
+            "branch, functions/rroi_align.py:22-25, is dead code and is not reproduced)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+
+
+# --------------------------------------------------------------------------- native path
+def forward(features: torch.Tensor, rois: torch.Tensor, pooled_height: int, pooled_width: int,
+            spatial_scale: float, path: int = PATH_AUTO) -> torch.Tensor:
+    """(B,C,H,W) x (R,6) -> (R,C,PH,PW).  NCHW-contiguous or channels_last features."""
+    _require_cuda_f32(features, "features")
+    _require_cuda_f32(rois, "rois")
+    if features.dim() != 4:
+        raise ValueError(f"features must be (B,C,H,W), got {tuple(features.shape)}")
+    if rois.dim() != 2 or rois.size(1) != 6:
+        raise ValueError(f"rois must be (R,6) [batch,cx,cy,h,w,angle_deg], got {tuple(rois.shape)}")
+    if rois.device != features.device:
+        raise ValueError("features and rois must be on the same device")
+    B, C, H, W = features.shape
+    R = rois.size(0)
+    ph, pw = int(pooled_height), int(pooled_width)
+    if ph <= 0 or pw <= 0:
+        raise ValueError("pooled_height and pooled_width must be positive")
+    if features.is_contiguous():
+        layout = LAYOUT_NCHW
+    elif features.is_contiguous(memory_format=torch.channels_last):
+        layout = LAYOUT_NHWC
+    else:
+        features, layout = features.contiguous(), LAYOUT_NCHW
+    rois = rois.contiguous()
+    with torch.cuda.device_of(features):
+        out = torch.empty((R, C, ph, pw), dtype=torch.float32, device=features.device)
+        if R == 0 or out.numel() == 0:
+            return out
+        nbytes = 0 if path == PATH_DIRECT else _lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, layout)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=features.device)
+        st = _lib.rroi_align_forward_hip(features.data_ptr(), layout, float(spatial_scale), B, R, H,
+                                         W, C, ph, pw, rois.data_ptr(), out.data_ptr(),
+                                         ws.data_ptr(), nbytes, path, _stream())
+    _check(st, "rroi_align_forward_hip")
+    return out
+
+
+def backward(grad_output: torch.Tensor, rois: torch.Tensor, feature_size, spatial_scale: float,
+             path: int = PATH_AUTO) -> torch.Tensor:
+    """(R,C,PH,PW) -> grad w.r.t. features (B,C,H,W), NCHW contiguous."""
+    _require_cuda_f32(grad_output, "grad_output")
+    _require_cuda_f32(rois, "rois")
+    B, C, H, W = (int(v) for v in feature_size)
+    if grad_output.dim() != 4 or grad_output.size(1) != C or grad_output.size(0) != rois.size(0):
+        raise ValueError("grad_output must be (R,C,PH,PW) matching rois and the feature size")
+    grad_output = grad_output.contiguous()
+    rois = rois.contiguous()
+    R, _, ph, pw = grad_output.shape
+    with torch.cuda.device_of(grad_output):
+        grad_in = torch.empty((B, C, H, W), dtype=torch.float32, device=grad_output.device)
+        if grad_in.numel() == 0:
+            return grad_in
+        nbytes = 0 if path == PATH_DIRECT else _lib.rroi_align_backward_workspace_bytes(B, C, H, W, R)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=grad_output.device)
+        st = _lib.rroi_align_backward_hip(grad_output.data_ptr(), float(spatial_scale), B, R, H, W,
+                                          C, ph, pw, rois.data_ptr(), grad_in.data_ptr(),
+                                          ws.data_ptr(), nbytes, path, _stream())
+    _check(st, "rroi_align_backward_hip")
+    return grad_in
+
+
+def bin_centres(rois: torch.Tensor, pooled_height: int, pooled_width: int, spatial_scale: float,
+                height: int, width: int) -> torch.Tensor:
+    """(R,PH,PW,2) sample points (kernel.cu:86-107); zero outside the ROI's pooled width."""
+    _require_cuda_f32(rois, "rois")
+    rois = rois.contiguous()
+    R = rois.size(0)
+    with torch.cuda.device_of(rois):
+        geom = torch.empty((R, int(pooled_height), int(pooled_width), 2), dtype=torch.float32,
+                           device=rois.device)
+        st = _lib.rroi_align_bin_centres_hip(float(spatial_scale), R, int(height), int(width),
+                                             int(pooled_height), int(pooled_width),
+                                             rois.data_ptr(), geom.data_ptr(), _stream())
+    _check(st, "rroi_align_bin_centres_hip")
+    return geom
+
+
+def sincos_probe(angle_deg: torch.Tensor) -> torch.Tensor:
+    _require_cuda_f32(angle_deg, "angle_deg")
+    angle_deg = angle_deg.contiguous().view(-1)
+    with torch.cuda.device_of(angle_deg):
+        out = torch.empty((angle_deg.numel(), 2), dtype=torch.float32, device=angle_deg.device)
+        st = _lib.rroi_align_sincos_probe_hip(angle_deg.data_ptr(), angle_deg.numel(),
+                                              out.data_ptr(), _stream())
+    _check(st, "rroi_align_sincos_probe_hip")
+    return out
+
+
+# --------------------------------------------------------------------------- reference FFI names
+def rroi_align_forward_cuda(pooled_height, pooled_width, spatial_scale, features, rois, output,
+                            idx_x, idx_y) -> int:
+    """Same name, argument order and return value as the reference's FFI function
+    (src/rroi_align_cuda.c:7-44): fills ``output``, ``idx_x``, ``idx_y`` in place;
+    returns 0 when ``rois.size(1) != 6`` (:22-26), else 1."""
+    for t, name in ((features, "features"), (rois, "rois"), (output, "output"), (idx_x, "idx_x"),
+                    (idx_y, "idx_y")):
+        _require_cuda_f32(t, name)
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous (the reference reads raw storage)")
+    if rois.size(1) != 6:
+        return 0
+    num_rois = rois.size(0)
+    _, C, H, W = features.shape
+    with torch.cuda.device_of(features):
+        st = _lib.RROIAlignForwardLaucher(features.data_ptr(), float(spatial_scale), num_rois, H, W,
+                                          C, int(pooled_height), int(pooled_width),
+                                          rois.data_ptr(), output.data_ptr(), idx_x.data_ptr(),
+                                          idx_y.data_ptr(), _stream())
+    _check(st, "RROIAlignForwardLaucher")
+    return 1
+
+
+def rroi_align_backward_cuda(pooled_height, pooled_width, spatial_scale, top_grad, rois,
+                             bottom_grad, idx_x, idx_y) -> int:
+    """Reference FFI signature (src/rroi_align_cuda.c:49-87).  ``bottom_grad`` must be
+    zero on entry, as functions/rroi_align.py:35 guarantees in the reference."""
+    for t, name in ((top_grad, "top_grad"), (rois, "rois"), (bottom_grad, "bottom_grad"),
+                    (idx_x, "idx_x"), (idx_y, "idx_y")):
+        _require_cuda_f32(t, name)
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous (the reference reads raw storage)")
+    if rois.size(1) != 6:
+        return 0
+    num_rois = rois.size(0)
+    B, C, H, W = bottom_grad.shape
+    with torch.cuda.device_of(top_grad):
+        st = _lib.RROIAlignBackwardLaucher(top_grad.data_ptr(), float(spatial_scale), B, num_rois, H,
+                                           W, C, int(pooled_height), int(pooled_width),
+                                           rois.data_ptr(), bottom_grad.data_ptr(),
+                                           idx_x.data_ptr(), idx_y.data_ptr(), _stream())
+    _check(st, "RROIAlignBackwardLaucher")
+    return 1

@@ -1,0 +1,66 @@
+"""rroi_align.functions.rroi_align -- autograd surface of RoIRotate.
+
+Mirrors ``rroi_align/functions/rroi_align.py:6-40`` of the reference: an object
+constructed as ``RRoiAlignFunction(pooled_height, pooled_width, spatial_scale)``
+and called with ``(features, rois)``; gradient w.r.t. ``features`` only
+(``:40`` returns ``(grad_input, None)``).  The reference is a legacy
+instance-style ``torch.autograd.Function`` (removed in torch >= 1.5); here the
+same callable wraps a static Function.  Unlike the reference nothing
+output-sized is kept for backward: the bin centres (``ctx.idx_x/idx_y``,
+``:19-20``) are a pure function of the rois and are recomputed.
+"""
+import torch
+from torch.autograd import Function
+
+from .._ext import rroi_align
+
+
+class _RRoiAlignOp(Function):
+    @staticmethod
+    def forward(ctx, features, rois, pooled_height, pooled_width, spatial_scale):
+        ctx.pooled_height = pooled_height
+        ctx.pooled_width = pooled_width
+        ctx.spatial_scale = spatial_scale
+        ctx.feature_size = features.size()
+        ctx.save_for_backward(rois)
+        return rroi_align.forward(features, rois, pooled_height, pooled_width, spatial_scale)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        grad_input = None
+        if ctx.needs_input_grad[0]:
+            grad_input = rroi_align.backward(grad_output, rois, ctx.feature_size,
+                                             ctx.spatial_scale)
+        return grad_input, None, None, None, None
+
+
+class RRoiAlignFunction(object):
+    """``RRoiAlignFunction(ph, pw, scale)(features, rois) -> (R, C, ph, pw)``."""
+
+    def __init__(self, pooled_height, pooled_width, spatial_scale):
+        self.pooled_width = pooled_width
+        self.pooled_height = pooled_height
+        self.spatial_scale = spatial_scale
+        self.feature_size = None
+        self.rois = None
+
+    def __call__(self, features, rois):
+        self.feature_size = features.size()
+        self.rois = rois
+        return _RRoiAlignOp.apply(features, rois, int(self.pooled_height), int(self.pooled_width),
+                                  float(self.spatial_scale))
+
+    # the legacy Function's two methods, callable by hand as in torch 0.4
+    def forward(self, features, rois):
+        self.feature_size = features.size()
+        self.rois = rois
+        return rroi_align.forward(features, rois, int(self.pooled_height), int(self.pooled_width),
+                                  float(self.spatial_scale))
+
+    def backward(self, grad_output):
+        assert self.feature_size is not None and grad_output.is_cuda
+        grad_input = rroi_align.backward(grad_output, self.rois, self.feature_size,
+                                         float(self.spatial_scale))
+        return grad_input, None

@@ -1,0 +1,127 @@
+/*
+ * include/rroi_align_hip.h -- C-ABI of librroi_align_hip.so, the MI355X (gfx950)
+ * implementation of the RoIRotate / rroi_align hot path of FOTS.pytorch.
+ *
+ * Plain pointers and sizes only; no torch types.  Every device pointer is
+ * borrowed for the duration of the asynchronous launch; the library never
+ * allocates, frees or synchronises.  `stream` is a hipStream_t passed as
+ * void* (NULL = the null stream).  All citations below are relative to the
+ * reference checkout (chenjun2hao/FOTS.pytorch).
+ *
+ * Return convention (extends rroi_align/src/rroi_align_cuda.c:23-26,43 and
+ * rroi_align_kernel.cu:186): 1 = success, 0 = invalid argument, negative =
+ * -(hipError_t) of a failed launch.  The reference's launchers call exit(-1)
+ * on a launch error (kernel.cu:179-184); this library never exits.
+ */
+#ifndef RROI_ALIGN_HIP_H
+#define RROI_ALIGN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- *
+ * 1. The reference's own launcher ABI, symbol for symbol.
+ *    Replaces rroi_align/src/rroi_align_kernel.h:8-18 (implemented in the
+ *    reference by rroi_align_kernel.cu:164-187 and :280-312), so the
+ *    reference's glue rroi_align/src/rroi_align_cuda.c:37-41,80-84 links
+ *    against this library unchanged (cudaStream_t -> hipStream_t as void*).
+ *
+ *    bottom_data : (B, C, H, W) fp32, contiguous NCHW
+ *    bottom_rois : (R, 6) fp32 rows [batch_idx, cx, cy, h, w, angle_deg]
+ *    top_data, con_idx_x, con_idx_y : (R, C, PH, PW) fp32.  Every element is
+ *        written (zeros where the reference leaves its memset untouched), so
+ *        the buffers need not be zeroed first; con_idx_* may be NULL.
+ * ------------------------------------------------------------------------- */
+int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
+                            const int num_rois, const int height, const int width,
+                            const int channels, const int pooled_height, const int pooled_width,
+                            const float* bottom_rois, float* top_data, float* con_idx_x,
+                            float* con_idx_y, void* stream);
+
+/*  top_diff : (R, C, PH, PW) fp32;  bottom_diff : (B, C, H, W) fp32, must be
+ *  zero on entry exactly as in the reference (functions/rroi_align.py:35);
+ *  con_idx_x/y : the tensors the forward wrote (read per element, as
+ *  kernel.cu:232-233 does). */
+int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
+                             const int batch_size, const int num_rois, const int height,
+                             const int width, const int channels, const int pooled_height,
+                             const int pooled_width, const float* bottom_rois,
+                             float* bottom_diff, const float* con_idx_x, const float* con_idx_y,
+                             void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * 2. The MI355X-native entry points used by the Python surface
+ *    (rroi_align.functions.rroi_align.RRoiAlignFunction, replacing
+ *    rroi_align/functions/rroi_align.py:13-40).  No con_idx tensors: the bin
+ *    centres are a pure function of the rois and are recomputed in backward.
+ * ------------------------------------------------------------------------- */
+
+/* feature_layout */
+#define RROI_LAYOUT_NCHW 0 /* (B, C, H, W) contiguous -- the reference contract */
+#define RROI_LAYOUT_NHWC 1 /* (B, H, W, C) contiguous (torch channels_last storage) */
+
+/* path */
+#define RROI_PATH_AUTO 0   /* pick by problem size                                  */
+#define RROI_PATH_DIRECT 1 /* one kernel, NCHW gather, no workspace (small R)       */
+#define RROI_PATH_TILED 2  /* relayout to pixel-major + wave-tiled gather (large R) */
+
+/* Bytes of scratch the tiled path needs for this problem (0 for the direct
+ * path).  The caller owns the scratch; its contents are dead after the call. */
+size_t rroi_align_forward_workspace_bytes(int batch_size, int channels, int height, int width,
+                                          int num_rois, int feature_layout);
+size_t rroi_align_backward_workspace_bytes(int batch_size, int channels, int height, int width,
+                                           int num_rois);
+
+/* Forward.  top_data (R, C, PH, PW) is fully written.  rois whose batch index
+ * falls outside [0, batch_size) produce zeros (the reference reads out of
+ * bounds there).  Returns 1 / 0 / -hipError. */
+int rroi_align_forward_hip(const float* features, int feature_layout, float spatial_scale,
+                           int batch_size, int num_rois, int height, int width, int channels,
+                           int pooled_height, int pooled_width, const float* rois,
+                           float* top_data, void* workspace, size_t workspace_bytes, int path,
+                           void* stream);
+
+/* The same call split into its launches, so a harness can bracket each kernel
+ * with events on `stream`: RROI_STAGE_PROLOGUE = relayout + affine table,
+ * RROI_STAGE_GATHER = the gather/blend/stream-out kernel (needs the workspace a
+ * PROLOGUE call on the same arguments filled).  The direct path has one kernel,
+ * run under RROI_STAGE_GATHER. */
+#define RROI_STAGE_PROLOGUE 1
+#define RROI_STAGE_GATHER 2
+#define RROI_STAGE_ALL 3
+int rroi_align_forward_stages_hip(const float* features, int feature_layout, float spatial_scale,
+                                  int batch_size, int num_rois, int height, int width,
+                                  int channels, int pooled_height, int pooled_width,
+                                  const float* rois, float* top_data, void* workspace,
+                                  size_t workspace_bytes, int path, int stages, void* stream);
+
+/* Backward w.r.t. the features (kernel.cu:193-278 semantics, including its
+ * asymmetric border tests :267-274).  bottom_diff (B, C, H, W) NCHW is fully
+ * overwritten; it does not have to be zeroed. */
+int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batch_size,
+                            int num_rois, int height, int width, int channels,
+                            int pooled_height, int pooled_width, const float* rois,
+                            float* bottom_diff, void* workspace, size_t workspace_bytes, int path,
+                            void* stream);
+
+/* Bin centres only: geom (R, PH, PW, 2) = (bin_cx, bin_cy), 0 where the bin is
+ * outside the ROI's pooled width (kernel.cu:86-107).  Diagnostic / test hook. */
+int rroi_align_bin_centres_hip(float spatial_scale, int num_rois, int height, int width,
+                               int pooled_height, int pooled_width, const float* rois,
+                               float* geom, void* stream);
+
+/* (float)cos((double)x), (float)sin((double)x) of n angles given in degrees,
+ * through the same device code the kernels use (test hook for the one
+ * library-dependent step of the arithmetic recipe). out = (n, 2). */
+int rroi_align_sincos_probe_hip(const float* angle_deg, int n, float* out, void* stream);
+
+/* Identification: "rroi_align_hip <version> gfx950". */
+const char* rroi_align_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RROI_ALIGN_HIP_H */

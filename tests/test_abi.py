@@ -1,0 +1,102 @@
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares; the
+host-side argument checks work; the Python surface refuses to run without a GPU
+instead of falling back.  No kernel is launched here."""
+import ctypes
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = []
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names += re.findall(r"^\s*(?:const\s+)?(?:int|size_t|char\s*\*|void)\s*\*?\s*(\w+)\s*\(", src, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_lists_expected_entry_points():
+    names = declared_functions()
+    for n in ("RROIAlignForwardLaucher", "RROIAlignBackwardLaucher", "rroi_align_forward_hip",
+              "rroi_align_backward_hip", "rroi_align_forward_workspace_bytes"):
+        assert n in names, names
+
+
+def test_library_exports_every_declared_symbol():
+    from rroi_align._ext import rroi_align as ext
+    lib = ctypes.CDLL(ext.LIB_PATH)
+    for n in declared_functions():
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported"
+    assert set(declared_functions()) == set(ext.EXPORTS)
+    assert "gfx950" in ext.version()
+
+
+def test_code_object_is_gfx950():
+    from rroi_align._ext import rroi_align as ext
+    blob = open(ext.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"sm_" not in blob
+
+
+def test_workspace_query_is_host_only():
+    from rroi_align._ext import rroi_align as ext
+    n = ext._lib.rroi_align_forward_workspace_bytes(1, 256, 160, 160, 512, ext.LAYOUT_NCHW)
+    assert n >= 256 * 160 * 160 * 4 + 512 * 32
+    assert n < 256 * 160 * 160 * 4 + 512 * 32 + 4096
+    # channels_last with C % 4 == 0 is consumed in place: only the affine table
+    assert ext._lib.rroi_align_forward_workspace_bytes(1, 256, 160, 160, 512, ext.LAYOUT_NHWC) < 32768
+    assert ext._lib.rroi_align_forward_workspace_bytes(0, 256, 160, 160, 512, 0) == 0
+
+
+def test_invalid_arguments_return_zero_without_touching_the_gpu():
+    from rroi_align._ext import rroi_align as ext
+    f = ext._lib.rroi_align_forward_hip
+    # bad shape / layout / path -> 0 (reference convention, rroi_align_cuda.c:23-26)
+    assert f(None, 0, 1.0, 1, 4, -1, 8, 3, 8, 32, None, None, None, 0, 0, None) == 0
+    assert f(None, 7, 1.0, 1, 4, 8, 8, 3, 8, 32, None, None, None, 0, 0, None) == 0
+    assert f(None, 0, 1.0, 1, 4, 8, 8, 3, 8, 32, None, None, None, 0, 9, None) == 0
+    assert f(None, 0, 1.0, 1, 4, 8, 8, 3, 8, 32, None, None, None, 0, 0, None) == 0  # null pointers
+    assert f(None, 0, 1.0, 1, 0, 8, 8, 3, 8, 32, None, None, None, 0, 0, None) == 1  # R == 0 is a no-op
+    assert ext._lib.RROIAlignForwardLaucher(None, 1.0, 4, 8, 8, 3, 0, 32, None, None, None, None, None) == 0
+
+
+def test_cpu_tensors_are_refused_not_emulated():
+    from rroi_align.functions.rroi_align import RRoiAlignFunction
+    from rroi_align.modules.rroi_align import _RRoiAlign
+    feats, rois = torch.zeros(1, 3, 8, 8), torch.zeros(2, 6)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        _RRoiAlign(8, 32, 1.0)(feats, rois)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        RRoiAlignFunction(8, 32, 1.0)(feats, rois)
+
+
+def test_module_surface_matches_reference():
+    """rroi_align/modules/rroi_align.py:6-14 and functions/rroi_align.py:7-11."""
+    from rroi_align.functions.rroi_align import RRoiAlignFunction
+    from rroi_align.modules.rroi_align import _RRoiAlign
+    m = _RRoiAlign(11.0, "64", 1 / 4)
+    assert (m.pooled_height, m.pooled_width, m.spatial_scale) == (11, 64, 0.25)
+    assert isinstance(m, torch.nn.Module) and not list(m.parameters())
+    fn = RRoiAlignFunction(8, 64, 0.25)
+    assert (fn.pooled_height, fn.pooled_width, fn.spatial_scale, fn.feature_size) == (8, 64, 0.25, None)
+    from rroi_align._ext import rroi_align as ext
+    assert callable(ext.rroi_align_forward_cuda) and callable(ext.rroi_align_backward_cuda)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under fots.pytorch_amd/ may import,
+    link, load or execute it (mentions in comments are fine)."""
+    pkg = os.path.join(ROOT, "fots.pytorch_amd")
+    bad = re.compile(r"(^\s*(from|import)\s+\S*oracle)|librroi_oracle|oracle/_build|oracle/_ref|"
+                     r"CDLL\([^)]*oracle|subprocess[^\n]*oracle", re.M)
+    checked = 0
+    for path in glob.glob(os.path.join(pkg, "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+            checked += 1
+            assert not bad.search(open(path, errors="ignore").read()), path
+    assert checked >= 6

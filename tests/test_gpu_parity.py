@@ -1,0 +1,236 @@
+"""GPU (MI355X): the HIP path against the oracle, through the C-ABI and the reference's
+Python surface.  Forward: BIT-EXACT (north_star allows 1e-5; the arithmetic recipe is
+shared, so any difference is a bug).  Backward: 1e-4 relative to the gradient scale
+(fp32 atomics commute but do not associate; BASELINE.json configs[2])."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import workloads as Wk
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+FWD_TOL = 0.0          # bit-exact
+BWD_RTOL = 1e-4        # of max |grad|
+
+
+@pytest.fixture(scope="module")
+def ext():
+    from rroi_align._ext import rroi_align as e
+    return e
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def eq(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def run_fwd(ext, f, r, ph, pw, s, path):
+    return ext.forward(dev(f), dev(r), ph, pw, s, path=path).cpu().numpy()
+
+
+def mismatch(a, b):
+    bad = ~((a == b) | (np.isnan(a) & np.isnan(b)))
+    return int(bad.sum()), (float(np.nanmax(np.abs(a - b))) if bad.any() else 0.0)
+
+
+SHAPES = {
+    # name: (features/rois factory, ph, pw, scale)
+    "cfg1": lambda: (*Wk.cfg1_inputs(), 8, 32, 1.0),                                  # BASELINE configs[0]
+    "mid_c64": lambda: (*Wk.bench_inputs(R=40, C=64, seed=11), 8, 64, 0.25),
+    "train_11xceil": lambda: (*Wk.bench_inputs(R=32, C=64, H=120, W=160, img=640, seed=5), 11, 83, 0.25),
+    "image_c3_44x349": lambda: (*Wk.bench_inputs(R=5, C=3, H=276, W=500, img=500, seed=6), 44, 349, 1.0),
+    "c70_odd": lambda: (*Wk.bench_inputs(R=9, C=70, H=50, W=70, img=280, seed=7), 8, 33, 0.25),
+    "c5_pad": lambda: (*Wk.bench_inputs(R=17, C=5, H=64, W=64, img=256, seed=8), 32, 57, 0.25),
+    "batch3": lambda: (*Wk.bench_inputs(R=48, C=32, H=64, W=64, img=256, seed=9, batch=3), 8, 40, 0.25),
+    "r1_infer": lambda: (*Wk.bench_inputs(R=1, C=64, H=176, W=320, img=1280, seed=10), 11, 64, 0.25),
+}
+
+
+@pytest.mark.parametrize("path", ["direct", "tiled", "auto"])
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_forward_bit_exact(ext, oracle, name, path):
+    f, r, ph, pw, s = SHAPES[name]()
+    want = oracle.forward_c(f, r, ph, pw, s, threads=8)
+    got = run_fwd(ext, f, r, ph, pw, s, {"direct": ext.PATH_DIRECT, "tiled": ext.PATH_TILED,
+                                         "auto": ext.PATH_AUTO}[path])
+    n, d = mismatch(got, want)
+    assert n == 0 and d <= FWD_TOL, f"{n} elements differ, max |d| = {d}"
+
+
+@pytest.mark.parametrize("path", ["direct", "tiled"])
+def test_forward_edge_and_degenerate_rois(ext, oracle, path):
+    rng = np.random.default_rng(1)
+    f = rng.standard_normal((1, 36, 160, 160), dtype=np.float32)
+    p = ext.PATH_DIRECT if path == "direct" else ext.PATH_TILED
+    for rois in (Wk.edge_rois(), Wk.degenerate_rois()):
+        want = oracle.forward_c(f, rois, 8, 64, 0.25)
+        got = run_fwd(ext, f, rois, 8, 64, 0.25, p)
+        n, d = mismatch(got, want)
+        assert n == 0, f"{n} elements differ (max {d})"
+
+
+def test_forward_nonfinite_features(ext, oracle):
+    """0 * inf = NaN in the reference's blend (kernel.cu:138-141): reproduced, not skipped."""
+    f, r = Wk.bench_inputs(R=16, C=8, seed=12)
+    f[0, :, 40:44, 50:54] = np.inf
+    f[0, :, 90, 100] = np.nan
+    want = oracle.forward_c(f, r, 8, 64, 0.25)
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+        assert mismatch(run_fwd(ext, f, r, 8, 64, 0.25, p), want)[0] == 0
+
+
+@pytest.mark.parametrize("name", ["oracle_cfg1", "oracle_mid", "oracle_edge"])
+def test_golden_fixtures(ext, name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    ph, pw = (int(v) for v in z["pooled"])
+    s = float(z["scale"])
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+        assert eq(run_fwd(ext, z["features"], z["rois"], ph, pw, s, p), z["out"])
+    H, W = z["features"].shape[2:]
+    geom = ext.bin_centres(dev(z["rois"]), ph, pw, s, H, W).cpu().numpy()
+    assert eq(geom, z["geom"])
+    gout = (2.0 * np.nan_to_num(z["out"])).astype(np.float32)
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+        gin = ext.backward(dev(gout), dev(z["rois"]), z["features"].shape, s, path=p).cpu().numpy()
+        scale = max(1.0, float(np.abs(z["grad_in"]).max()))
+        assert np.abs(gin - z["grad_in"]).max() <= BWD_RTOL * scale
+
+
+def test_sincos_recipe_matches_host_libm(ext):
+    """The one library-dependent step: (float)cos((double)a), (float)sin((double)a).
+    Device (ocml) and host (glibc) must round to the same fp32 for every angle tried."""
+    rng = np.random.default_rng(0)
+    deg = np.concatenate([
+        rng.uniform(-180, 180, 2_000_000), rng.uniform(-720, 720, 500_000),
+        np.arange(-360, 361, 0.25), rng.uniform(-1e-3, 1e-3, 100_000), rng.uniform(-1e6, 1e6, 100_000),
+    ]).astype(np.float32)
+    got = ext.sincos_probe(dev(deg)).cpu().numpy()
+    ang = ((deg.astype(np.float64) / 180.0) * 3.1415926535).astype(np.float32).astype(np.float64)
+    want = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    bad = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+    assert bad == 0, f"{bad} of {2 * len(deg)} sin/cos values differ between ocml and glibc"
+
+
+@pytest.mark.parametrize("path", ["direct", "tiled"])
+@pytest.mark.parametrize("name", ["cfg1", "mid_c64", "c70_odd", "c5_pad", "batch3", "train_11xceil"])
+def test_backward_vs_oracle(ext, oracle, name, path):
+    f, r, ph, pw, s = SHAPES[name]()
+    out = oracle.forward_c(f, r, ph, pw, s, threads=8)
+    gout = (2 * out).astype(np.float32)
+    want = oracle.backward_c(gout, r, f.shape, s)
+    p = ext.PATH_DIRECT if path == "direct" else ext.PATH_TILED
+    got = ext.backward(dev(gout), dev(r), f.shape, s, path=p).cpu().numpy()
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() <= BWD_RTOL * scale
+    assert eq(got == 0, want == 0) or np.abs(got[(got == 0) != (want == 0)]).max() < 1e-30
+
+
+def test_backward_edge_rois(ext, oracle):
+    rng = np.random.default_rng(2)
+    f = rng.standard_normal((1, 8, 160, 160), dtype=np.float32)
+    rois = np.concatenate([Wk.edge_rois(), Wk.degenerate_rois()[[0, 1, 2, 3, 4]]])
+    gout = rng.standard_normal((len(rois), 8, 8, 64), dtype=np.float32)
+    want = oracle.backward_c(gout, rois, f.shape, 0.25)
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+        got = ext.backward(dev(gout), dev(rois), f.shape, 0.25, path=p).cpu().numpy()
+        assert np.abs(got - want).max() <= BWD_RTOL * max(1.0, float(np.abs(want).max()))
+
+
+def test_autograd_surface(ext, oracle):
+    """The reference's demo flow (rroi_align/test2.py:70-75): module call,
+    pooled.pow(2).sum().backward(), grad on the feature map only."""
+    from rroi_align.modules.rroi_align import _RRoiAlign
+    f, r = Wk.bench_inputs(R=24, C=16, seed=13)
+    feats = dev(f).requires_grad_(True)
+    rois = dev(r)
+    pooled = _RRoiAlign(8, 64, 0.25)(feats, rois.view(-1, 6))
+    assert pooled.shape == (24, 16, 8, 64) and pooled.dtype == torch.float32
+    pooled.pow(2).sum().backward()
+    out = oracle.forward_c(f, r, 8, 64, 0.25)
+    assert eq(pooled.detach().cpu().numpy(), out)
+    want = oracle.backward_c((2 * out).astype(np.float32), r, f.shape, 0.25)
+    got = feats.grad.cpu().numpy()
+    assert np.abs(got - want).max() <= BWD_RTOL * max(1.0, float(np.abs(want).max()))
+    assert rois.grad is None
+
+
+def test_legacy_function_methods(ext, oracle):
+    from rroi_align.functions.rroi_align import RRoiAlignFunction
+    f, r = Wk.cfg1_inputs()
+    fn = RRoiAlignFunction(8, 32, 1.0)
+    out = fn.forward(dev(f), dev(r))
+    assert tuple(fn.feature_size) == f.shape
+    gin, none = fn.backward(out * 2)
+    assert none is None and gin.shape == f.shape
+    want = oracle.backward_c((2 * oracle.forward_c(f, r, 8, 32, 1.0)).astype(np.float32), r, f.shape, 1.0)
+    assert np.abs(gin.cpu().numpy() - want).max() <= BWD_RTOL * max(1.0, float(np.abs(want).max()))
+
+
+def test_reference_ffi_names(ext, oracle):
+    """_ext.rroi_align.rroi_align_forward_cuda / _backward_cuda with the reference's
+    argument order (src/rroi_align_cuda.h:1-7), including idx_x / idx_y."""
+    f, r = Wk.bench_inputs(R=12, C=6, seed=14)
+    F, Rr = dev(f), dev(r)
+    shape = (12, 6, 8, 64)
+    out, ix, iy = (torch.full(shape, 7.0, device="cuda") for _ in range(3))  # not pre-zeroed on purpose
+    assert ext.rroi_align_forward_cuda(8, 64, 0.25, F, Rr, out, ix, iy) == 1
+    want, wx, wy = oracle.forward_literal_c(f, r, 8, 64, 0.25)
+    assert eq(out.cpu().numpy(), want) and eq(ix.cpu().numpy(), wx) and eq(iy.cpu().numpy(), wy)
+    gin = torch.zeros(f.shape, device="cuda")
+    assert ext.rroi_align_backward_cuda(8, 64, 0.25, out * 2, Rr, gin, ix, iy) == 1
+    wb = oracle.backward_literal_c((2 * want).astype(np.float32), r, wx, wy, f.shape, 0.25)
+    assert np.abs(gin.cpu().numpy() - wb).max() <= BWD_RTOL * max(1.0, float(np.abs(wb).max()))
+    assert ext.rroi_align_forward_cuda(8, 64, 0.25, F, Rr[:, :5].contiguous(), out, ix, iy) == 0
+
+
+def test_channels_last_is_consumed_in_place(ext, oracle):
+    f, r = Wk.bench_inputs(R=20, C=64, seed=15, batch=2)
+    want = oracle.forward_c(f, r, 8, 64, 0.25, threads=8)
+    cl = dev(f).contiguous(memory_format=torch.channels_last)
+    assert not cl.is_contiguous()
+    assert eq(ext.forward(cl, dev(r), 8, 64, 0.25).cpu().numpy(), want)
+    f3, r3 = Wk.bench_inputs(R=6, C=3, H=64, W=96, img=96, seed=16)
+    cl3 = dev(f3).contiguous(memory_format=torch.channels_last)
+    assert eq(ext.forward(cl3, dev(r3), 32, 100, 1.0, path=ext.PATH_TILED).cpu().numpy(),
+              oracle.forward_c(f3, r3, 32, 100, 1.0))
+
+
+def test_other_stream_and_reentrancy(ext, oracle):
+    f, r = Wk.bench_inputs(R=32, C=32, seed=17)
+    want = oracle.forward_c(f, r, 8, 64, 0.25, threads=8)
+    F, Rr = dev(f), dev(r)
+    torch.cuda.synchronize()
+    s1 = torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        outs = [ext.forward(F, Rr, 8, 64, 0.25, path=ext.PATH_TILED) for _ in range(4)]
+    s1.synchronize()
+    for o in outs:
+        assert eq(o.cpu().numpy(), want)
+
+
+def test_invalid_batch_index_yields_zeros(ext):
+    f, r = Wk.bench_inputs(R=4, C=8, seed=18)
+    r[1, 0] = 5
+    r[2, 0] = -3
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+        out = run_fwd(ext, f, r, 8, 64, 0.25, p)
+        assert not out[1].any() and not out[2].any() and out[0].any() and out[3].any()
+
+
+def test_input_validation(ext):
+    F = torch.zeros(1, 4, 16, 16, device="cuda")
+    R = torch.zeros(2, 6, device="cuda")
+    with pytest.raises(ValueError):
+        ext.forward(F, R[:, :5], 8, 8, 1.0)
+    with pytest.raises(TypeError):
+        ext.forward(F.double(), R, 8, 8, 1.0)
+    with pytest.raises(ValueError):
+        ext.forward(F[0], R, 8, 8, 1.0)
+    assert ext.forward(F, R[:0], 8, 8, 1.0).shape == (0, 4, 8, 8)

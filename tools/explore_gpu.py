@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""GPU-box exploration: device write/copy ceilings, per-stage timings of our path, the
+reference's own kernels (oracle/_ref, hipify-perl build) timed and compared.  Writes
+gpurun_out/explore.json.  Measurement tooling, not product code."""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "fots.pytorch_amd"), os.path.join(ROOT, "tests")]
+import workloads as Wk  # noqa: E402
+from rroi_align._ext import rroi_align as ext  # noqa: E402
+
+res = {}
+
+
+def timeit(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    t = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
+    return {"avg_us": float(t.mean()), "p50_us": float(np.median(t)), "min_us": float(t.min())}
+
+
+dev = torch.device("cuda:0")
+p = torch.cuda.get_device_properties(0)
+res["device"] = {"name": p.name, "cus": p.multi_processor_count, "mem_GB": p.total_memory / 2**30}
+
+# --- ceilings ---------------------------------------------------------------------------
+n = 64 * 1024 * 1024  # 256 MiB of fp32
+a = torch.empty(n, device=dev)
+b = torch.empty(n, device=dev)
+r = timeit(lambda: a.fill_(1.0))
+res["fill_256MiB"] = {**r, "GBs": n * 4 / r["avg_us"] / 1e3}
+r = timeit(lambda: a.zero_())
+res["memset_256MiB"] = {**r, "GBs": n * 4 / r["avg_us"] / 1e3}
+r = timeit(lambda: b.copy_(a))
+res["copy_256MiB"] = {**r, "GBs_rw": 2 * n * 4 / r["avg_us"] / 1e3}
+big = torch.empty(4 * n, device=dev)
+r = timeit(lambda: big.fill_(1.0), iters=20)
+res["fill_1GiB"] = {**r, "GBs": 4 * n * 4 / r["avg_us"] / 1e3}
+del a, b, big
+
+# --- our path ---------------------------------------------------------------------------
+f, rois = Wk.bench_inputs()
+F, R = torch.from_numpy(f).to(dev), torch.from_numpy(rois).to(dev)
+out = torch.empty((512, 256, 8, 64), device=dev)
+nb = ext._lib.rroi_align_forward_workspace_bytes(1, 256, 160, 160, 512, 0)
+ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+
+
+def stage(s, path=ext.PATH_TILED):
+    rc = ext._lib.rroi_align_forward_stages_hip(F.data_ptr(), 0, 0.25, 1, 512, 160, 160, 256, 8, 64,
+                                                 R.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, path, s, st)
+    assert rc == 1, rc
+
+
+res["fwd_prologue"] = timeit(lambda: stage(1))
+res["fwd_gather"] = timeit(lambda: stage(2))
+res["fwd_all"] = timeit(lambda: stage(3))
+res["fwd_direct"] = timeit(lambda: stage(2, ext.PATH_DIRECT), iters=20)
+ours = out.clone()
+
+Fcl = F.contiguous(memory_format=torch.channels_last)
+res["fwd_channels_last_zero_copy"] = timeit(lambda: ext.forward(Fcl, R, 8, 64, 0.25))
+
+g = torch.randn_like(out)
+res["bwd_tiled"] = timeit(lambda: ext.backward(g, R, f.shape, 0.25, path=ext.PATH_TILED), iters=20)
+res["bwd_direct"] = timeit(lambda: ext.backward(g, R, f.shape, 0.25, path=ext.PATH_DIRECT), iters=10)
+
+# small-R regimes of the callers
+for name, (Rn, C, H, W, ph, pw) in {"infer_R1_c64_11x64": (1, 64, 176, 320, 11, 64),
+                                      "train_R32_c64_11x96": (32, 64, 160, 160, 11, 96)}.items():
+    ff, rr = Wk.bench_inputs(R=Rn, C=C, H=H, W=W, img=4 * W, seed=3)
+    Ft, Rt = torch.from_numpy(ff).to(dev), torch.from_numpy(rr).to(dev)
+    for pname, pth in (("direct", ext.PATH_DIRECT), ("tiled", ext.PATH_TILED)):
+        res[f"{name}_{pname}"] = timeit(lambda: ext.forward(Ft, Rt, ph, pw, 0.25, path=pth), iters=30)
+
+# --- the reference's own kernels (oracle/_ref) --------------------------------------------
+ref_path = os.path.join(ROOT, "oracle", "_ref", "librroi_ref_hip.so")
+if os.path.exists(ref_path):
+    ref = ctypes.CDLL(ref_path)
+    vp, fl, it = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
+    ref.RROIAlignForwardLaucher.argtypes = [vp, fl, it, it, it, it, it, it, vp, vp, vp, vp, vp]
+    ref.RROIAlignBackwardLaucher.argtypes = [vp, fl, it, it, it, it, it, it, it, vp, vp, vp, vp, vp]
+    top, ix, iy = (torch.zeros_like(out) for _ in range(3))
+
+    def ref_fwd(with_memsets):
+        if with_memsets:  # functions/rroi_align.py:17-20
+            top.zero_(); ix.zero_(); iy.zero_()
+        ref.RROIAlignForwardLaucher(F.data_ptr(), 0.25, 512, 160, 160, 256, 8, 64, R.data_ptr(),
+                                    top.data_ptr(), ix.data_ptr(), iy.data_ptr(), st)
+
+    res["ref_fwd_kernel_only"] = timeit(lambda: ref_fwd(False), iters=10, warm=2)
+    res["ref_fwd_with_memsets"] = timeit(lambda: ref_fwd(True), iters=10, warm=2)
+    ref_fwd(True)
+    torch.cuda.synchronize()
+    diff = (top != ours)
+    nd = int(diff.sum())
+    res["ref_vs_ours_forward"] = {"elements": top.numel(), "differ": nd,
+                                  "bins_differ": int(diff.any(1).sum()),
+                                  "max_abs": float((top - ours).abs().max())}
+    gin = torch.zeros_like(F)
+
+    def ref_bwd():
+        gin.zero_()
+        ref.RROIAlignBackwardLaucher(g.data_ptr(), 0.25, 1, 512, 160, 160, 256, 8, 64, R.data_ptr(),
+                                     gin.data_ptr(), ix.data_ptr(), iy.data_ptr(), st)
+
+    res["ref_bwd_with_memset"] = timeit(ref_bwd, iters=5, warm=1)
+    mine = ext.backward(g, R, f.shape, 0.25)
+    ref_bwd()
+    torch.cuda.synchronize()
+    res["ref_vs_ours_backward"] = {"max_abs": float((gin - mine).abs().max()), "scale": float(gin.abs().max())}
+
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "explore.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))
