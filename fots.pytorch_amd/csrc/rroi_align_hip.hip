@@ -9,16 +9,17 @@
 // Design in one paragraph.  A bin's sample point depends on (roi, ph, pw) only,
 // never on the channel, and its 4 taps are whole pixels.  The op is therefore a
 // pixel gather replicated over C channels plus a 256 MiB streaming write.  In
-// NCHW the channel vector of a pixel is strided by H*W (a cache line per
-// channel), so the hot path first relays the map out pixel-major
-// (B,H,W,Cs; one 26 MB pass that the gather then reads from L2), after which a
-// tap is ONE contiguous run of channels.  Each wave owns a [32 channel] x
-// [64 bin] output tile: lanes = 8 bins x 8 channel-quads fetch taps as 16-byte
-// loads (8 lanes cover a pixel's 128-byte line of 32 channels), blend in the
-// reference's order, transpose through a wave-private LDS tile and stream the
-// tile out as full 256-byte rows of the (R,C,PH,PW) tensor.  Channel chunk k is
-// handled by blocks with blockIdx % nchunks == k, i.e. (8 chunks at C=256) by
-// one XCD, whose 4 MiB L2 then holds exactly its 3.2 MB slice of the map.
+// NCHW the channels of a pixel are H*W apart (one cache line per channel), so
+// the hot path first relays the map out CHUNK-MAJOR: (B, C/32, H*W+1, 32) --
+// 32 channels of a pixel are one 128-byte line, consecutive pixels of a chunk
+// are consecutive lines (all L2 channels of an XCD are used evenly), and every
+// (image, chunk) slice ends in a zero pixel that invalid taps point at.  Each
+// wave then owns a [32 channel] x [64 bin] output tile: lanes = 8 bins x 8
+// channel-quads fetch taps as 16-byte loads, blend in the reference's order,
+// transpose through a wave-private LDS tile and stream the tile out as full
+// 256-byte row segments of the (R,C,PH,PW) tensor.  Channel chunk k is handled
+// by blocks with blockIdx % nchunks == k, i.e. (8 chunks at C=256) by one XCD,
+// whose 4 MiB L2 then holds exactly its 3.2 MB slice of the map.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,18 +30,31 @@
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kChunk = 32;     // channels per work item  (8 lanes x 16 B = one 128 B line)
-constexpr int kTileBins = 64;  // bins per work item       (one 256 B output row segment)
+constexpr int kChunk = 32;     // channels per slice / work item (8 lanes x 16 B = one 128 B line)
+constexpr int kTileBins = 64;  // bins per work item              (one 256 B output row segment)
 constexpr int kTStride = 68;   // LDS tile row stride in dwords: 4*odd -> writes <=2-way, b128 reads aligned
 constexpr int kQuads = kChunk / 4;
-constexpr int kBinsPerIter = kWave / kQuads;  // 8
+constexpr int kBinsPerIter = kWave / kQuads;      // 8
 constexpr int kIters = kTileBins / kBinsPerIter;  // 8
+constexpr unsigned kLineBytes = kChunk * 4;       // 128
+
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct Affine {  // kernel.cu:78-84 (M), :68 (roi_pooled_width), :60 (roi_batch_ind)
     float m00, m01, m02, m10, m11, m12, rpw;
     int batch;
 };
 static_assert(sizeof(Affine) == 32, "Affine is read as two 16-byte scalars");
+
+struct FastDiv {  // Granlund-Montgomery unsigned division by an invariant, exact for all 32-bit x
+    unsigned m, sh1, sh2;
+};
+
+__device__ __forceinline__ unsigned fdiv(unsigned x, const FastDiv& f)
+{
+    const unsigned t = __umulhi(f.m, x);
+    return (t + ((x - t) >> f.sh1)) >> f.sh2;
+}
 
 __device__ __forceinline__ float as_f(unsigned u) { return __uint_as_float(u); }
 __device__ __forceinline__ unsigned as_u(float f) { return __float_as_uint(f); }
@@ -109,10 +123,9 @@ __device__ __forceinline__ bool bin_centre(const Affine& A, int ph, int pw, int 
     return fpw <= A.rpw;
 }
 
-// Tap record of one bin.  Taps are whole pixels: x1 = x0 + dx, y1 = y0 + dy with
-// dx,dy in {0,1} (bin centres are multiples of 0.5), so when dx == 0 the
-// reference's "right" taps ARE its left taps (same pixel, same validity) and
-// need no load of their own.
+// Taps are whole pixels: x1 = x0 + dx, y1 = y0 + dy with dx, dy in {0, 1} (bin
+// centres are multiples of 0.5), so when dx == 0 the reference's "right" taps
+// ARE its left taps (same pixel, same validity) and need no load of their own.
 enum : unsigned {
     kV00 = 1u,   // lt valid: y0>0 && x0>0 && y0<H && x0<W     (kernel.cu:116)
     kV01 = 2u,   // rt                                           (:119)
@@ -123,6 +136,8 @@ enum : unsigned {
     kActive = 64u,
     // backward's own, stricter bounds (kernel.cu:267-274)
     kB00 = 128u, kB01 = 256u, kB11 = 512u, kB10 = 1024u,
+    // "issue a load for this tap" (tiled forward)
+    kL0 = 1u << 16, kL1 = 1u << 17, kL2 = 1u << 18, kL3 = 1u << 19,
 };
 
 struct Taps {
@@ -167,10 +182,11 @@ __device__ __forceinline__ Taps make_taps(float bin_cx, float bin_cy, bool activ
 __device__ __forceinline__ void tap_weights(float rx, float ry, float& wlt, float& wrt, float& wrb,
                                             float& wlb)
 {
-    wlt = (1.0f - rx) * (1.0f - ry);
-    wrt = rx * (1.0f - ry);
+    const float ux = 1.0f - rx, uy = 1.0f - ry;
+    wlt = ux * uy;
+    wrt = rx * uy;
     wrb = rx * ry;
-    wlb = (1.0f - rx) * ry;
+    wlb = ux * ry;
 }
 
 // kernel.cu:136-141: inter_val = 0; += lt*wlt; += rt*wrt; += rb*wrb; += lb*wlb.
@@ -185,9 +201,89 @@ __device__ __forceinline__ float blend1(float lt, float rt, float rb, float lb, 
     return v;
 }
 
+// Where the sampled map lives for the tiled kernels.  A "slice" is the 32-channel
+// chunk k of image b; pixel p of a slice starts at slice_base + p * px_bytes.
+//   chunk-major copy  : px_bytes = 128, row pitch Wp >= W pixels, chunk_stride = (H*Wp+1)*32,
+//                       img_stride = nchunks*chunk_stride.  Wp is chosen so that vertically
+//                       adjacent pixels do not fall on the same L2 channel (W = 160 lines is
+//                       a multiple of the 16-channel interleave: a 90-degree ROI would queue
+//                       all 8 lines of a load instruction on one channel).
+//   channels-last user tensor (zero copy): px_bytes = C*4, chunk_stride = 32, img_stride = HW*C
+struct SliceLayout {
+    unsigned px_bytes;
+    unsigned row_bytes;     // pitch of one map row inside a slice (chunk-major rows are padded)
+    unsigned slice_bytes;   // extent of one slice from its base (range of the buffer descriptor)
+    unsigned chunk_stride;  // floats
+    unsigned img_stride;    // floats  (fits: shape_ok bounds it)
+};
+
 // ------------------------------------------------------------------------------------
-// K0a: per-ROI affine table (R x 32 B).  One thread per ROI.
+// K0: forward prologue, one launch:
+//   blocks [0, relayout_blocks)      NCHW -> chunk-major: a [32 ch] x [128 px] tile goes
+//                                    through LDS; reads are 512 B runs of a channel row,
+//                                    writes are one contiguous 16 KiB run of the slice;
+//   then zero_blocks                 the zero pixel that ends every slice;
+//   then the rest                    per-ROI affine table (R x 32 B).
 // ------------------------------------------------------------------------------------
+constexpr int kRelayoutPx = 128;
+
+__global__ __launch_bounds__(256) void rroi_prologue_kernel(
+    const float* __restrict__ nchw, float* __restrict__ cm, int C, int HW, int width, int pitch,
+    FastDiv div_w, int nchunks, int ptiles, int relayout_blocks, int zero_blocks, int batch_size,
+    const float* __restrict__ rois, int num_rois, int pooled_height, float spatial_scale,
+    Affine* __restrict__ aff)
+{
+    __shared__ float T[kChunk * (kRelayoutPx + 1)];
+    const int tid = threadIdx.x;
+    const size_t zp_index = (size_t)(HW / width) * pitch;  // pixel index of the zero pixel
+    const size_t slice_stride = (zp_index + 1) * kChunk;
+    if ((int)blockIdx.x >= relayout_blocks + zero_blocks) {
+        const int n = ((int)blockIdx.x - relayout_blocks - zero_blocks) * 256 + tid;
+        if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+        return;
+    }
+    if ((int)blockIdx.x >= relayout_blocks) {
+        const int i = ((int)blockIdx.x - relayout_blocks) * 256 + tid;  // (slice, channel-in-chunk)
+        if (i < batch_size * nchunks * kChunk)
+            cm[(size_t)(i / kChunk) * slice_stride + zp_index * kChunk + (i % kChunk)] = 0.0f;
+        return;
+    }
+    int bid = blockIdx.x;
+    const int pt = bid % ptiles;
+    bid /= ptiles;
+    const int k = bid % nchunks;
+    const int b = bid / nchunks;
+    const int lane = tid & 63, w = tid >> 6;
+    const int p0 = pt * kRelayoutPx, c0 = k * kChunk;
+    const float* src = nchw + ((size_t)b * C + c0) * HW + p0;
+    // wave w reads channels 8w..8w+7, two 64-pixel halves each
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = w * 8 + i;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int p = hlf * 64 + lane;
+            float v = 0.0f;
+            if (c0 + c < C && p0 + p < HW) v = src[(size_t)c * HW + p];
+            T[c * (kRelayoutPx + 1) + p] = v;
+        }
+    }
+    __syncthreads();
+    // wave w writes pixels 32w..32w+31: per instruction 8 pixels x 128 B = 1 KiB contiguous
+    float* dst = cm + ((size_t)b * nchunks + k) * slice_stride;
+    const int cq = lane & 7, pl = lane >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = w * 32 + j * 8 + pl;
+        const float* tr = T + (cq * 4) * (kRelayoutPx + 1) + p;
+        v4f v = {tr[0], tr[kRelayoutPx + 1], tr[2 * (kRelayoutPx + 1)], tr[3 * (kRelayoutPx + 1)]};
+        const unsigned gp = (unsigned)(p0 + p);
+        const unsigned y = fdiv(gp, div_w);
+        const size_t pix = (size_t)y * pitch + (gp - y * (unsigned)width);
+        if (p0 + p < HW) *reinterpret_cast<v4f*>(dst + pix * kChunk + cq * 4) = v;
+    }
+}
+
 __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois, int pooled_height,
                                    float spatial_scale, Affine* __restrict__ aff)
 {
@@ -196,200 +292,232 @@ __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois,
 }
 
 // ------------------------------------------------------------------------------------
-// K0b: relayout (B,C,H,W) -> pixel-major (B,H*W,Cs), Cs = C rounded up to 4.
-// 256 threads move a [64 channel] x [64 pixel] tile through LDS: coalesced 256 B
-// reads along pixels, coalesced 256 B writes along channels.  The last
-// gridDim.x - relayout_blocks blocks fill the affine table instead, so the whole
-// prologue is one launch.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rroi_prologue_kernel(
-    const float* __restrict__ nchw, float* __restrict__ pm, int C, int Cs, int HW, int ptiles,
-    int ctiles, int relayout_blocks, const float* __restrict__ rois, int num_rois,
-    int pooled_height, float spatial_scale, Affine* __restrict__ aff)
-{
-    __shared__ float T[64 * 65];
-    const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= relayout_blocks) {
-        const int n = ((int)blockIdx.x - relayout_blocks) * 256 + tid;
-        if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
-        return;
-    }
-    int bid = blockIdx.x;
-    const int pt = bid % ptiles;
-    bid /= ptiles;
-    const int ct = bid % ctiles;
-    const int b = bid / ctiles;
-    const int lane = tid & 63, w = tid >> 6;
-    const int p0 = pt * 64, c0 = ct * 64;
-    const float* src = nchw + ((size_t)b * C + c0) * HW + p0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = w * 16 + i;
-        float v = 0.0f;
-        if (c0 + c < C && p0 + lane < HW) v = src[(size_t)c * HW + lane];
-        T[c * 65 + lane] = v;
-    }
-    __syncthreads();
-    float* dst = pm + ((size_t)b * HW + p0) * Cs + c0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int p = w * 16 + i;
-        if (p0 + p < HW && c0 + lane < Cs) dst[(size_t)p * Cs + lane] = T[lane * 65 + p];
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // K1: the hot kernel.  One wave per block; block -> channel chunk k = blockIdx %
-// nchunks (XCD affinity), and a grid-stride loop over (roi, 64-bin tile) items.
+// nchunks (XCD affinity) and a grid-stride loop over (roi, 64-bin tile) items.
+//   phase A  lane = bin: geometry -> 32-byte tap record in LDS (4 byte offsets,
+//            flags, rx, ry).  With ZP an invalid tap (or any tap of a masked bin)
+//            points at the slice's zero pixel, so validity costs nothing later.
+//   phase B  lane = (bin b of 8, channel quad q of 8): first tap always, the
+//            other three only where the bin really has a second column / row,
+//            under the exec mask; taps that alias (dx == 0 / dy == 0) are
+//            resolved by register selects, which keeps the reference's four-term
+//            blend exact for non-finite features too; depth-2 software pipeline.
+//   phase C  the [32 ch][64 bin] tile leaves LDS as 16-byte stores, 256 B per row.
 // ------------------------------------------------------------------------------------
-struct TapRegs {
-    float4 lt, rt, lb, rb;
-};
+// Buffer addressing: every tap load and every output store goes through a raw buffer
+// descriptor (base, num_records) whose range check does the predication in hardware -- a lane
+// whose byte offset is >= num_records reads zeros / stores nothing and costs no memory access.
+// An invalid tap (kernel.cu:116-126 yields 0.0 for it), a tap the bin does not need, a channel
+// quad beyond C and a bin beyond PH*PW are all just "offset = kOOB".  The hot loop therefore
+// has no branches and no exec masking, and the compiler's s_waitcnt counts are exact.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0x80000000u;          // > any slice / tile size (shape_ok: < 2 GiB)
+constexpr unsigned kRsrcWord3 = 0x00020000u;    // raw buffer, 32-bit data format (gfx9 family)
 
-typedef float v4f __attribute__((ext_vector_type(4)));  // native vector: nontemporal builtins take it
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4_nt(float* p, const float4& v)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes)
 {
-    v4f t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcWord3);
 }
-__device__ __forceinline__ float4 ld4_nt(const float* p)
+__device__ __forceinline__ v4f buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
 {
-    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
-    return make_float4(t.x, t.y, t.z, t.w);
+    return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
-
-__device__ __forceinline__ TapRegs load_taps(const float* __restrict__ sp, const Taps& g,
-                                             unsigned pixel_stride, unsigned row_stride, bool chok)
+// Cache policy of the output stream (gfx940-family bits: 1 = sc0, 2 = nt, 16 = sc1).  The
+// 256 MiB of crops must not displace the 3.3 MB map slice from the XCD's 4 MiB L2: with plain
+// stores every written line is kept in L2 and 47 % of the tap reads missed L2; sc1 stores
+// are written through and dropped.
+template <int AUX>
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned byte_off, v4f v)
 {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    TapRegs r;
-    const unsigned f = chok ? g.flags : 0u;
-    const unsigned o_rt = g.o_lt + pixel_stride;
-    const unsigned o_lb = g.o_lt + row_stride;
-    const unsigned o_rb = o_lb + pixel_stride;
-    r.lt = z;
-    r.rt = z;
-    r.lb = z;
-    r.rb = z;
-    if (f & kV00) r.lt = ld4(sp + g.o_lt);
-    if ((f & (kV01 | kDx)) == (kV01 | kDx)) r.rt = ld4(sp + o_rt);
-    if ((f & (kV10 | kDy)) == (kV10 | kDy)) r.lb = ld4(sp + o_lb);
-    if ((f & (kV11 | kDx | kDy)) == (kV11 | kDx | kDy)) r.rb = ld4(sp + o_rb);
-    return r;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, byte_off, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, AUX);
 }
 
-// Resolve the taps that alias an already loaded pixel (dx == 0 and/or dy == 0).
-__device__ __forceinline__ void alias_taps(TapRegs& r, unsigned f)
-{
-    if (!(f & kDx)) r.rt = r.lt;
-    if (!(f & kDy)) r.lb = r.lt;
-    if (!(f & kDx))
-        r.rb = r.lb;  // x1 == x0: rb is the pixel below lt, i.e. lb (which is lt when dy == 0 too)
-    else if (!(f & kDy))
-        r.rb = r.rt;  // y1 == y0: rb is rt
-}
-
-template <bool VEC_STORE>
+template <bool VEC_STORE, int AUX>
 __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
-    const float* __restrict__ pm,      // pixel-major features (B, H*W, Cs)
-    const Affine* __restrict__ aff,    // (R)
-    float* __restrict__ out,           // (R, C, PH*PW)
-    int num_rois, int C, int Cs, int height, int width, int pooled_height, int pooled_width,
-    int batch_size, int nchunks, int ntiles)
+    const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
+    int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
+    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw)
 {
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride];
-    __shared__ __attribute__((aligned(16))) uint4 G[kTileBins];
+    __shared__ __attribute__((aligned(16))) uint4 G[kTileBins * 2];
 
-    const int lane = threadIdx.x;
-    const int k = blockIdx.x % nchunks;
-    const int slot = blockIdx.x / nchunks;
-    const int nslots = gridDim.x / nchunks;
-    const int NB = pooled_height * pooled_width;
-    const long items = (long)num_rois * ntiles;
-    const unsigned pixel_stride = (unsigned)Cs;
-    const unsigned row_stride = (unsigned)width * (unsigned)Cs;
+    const unsigned lane = threadIdx.x;
+    const unsigned k = blockIdx.x % (unsigned)nchunks;
+    const unsigned slot = blockIdx.x / (unsigned)nchunks;
+    const unsigned nslots = gridDim.x / (unsigned)nchunks;
+    const unsigned items = (unsigned)num_rois * (unsigned)ntiles;
+    const unsigned px_bytes = lay.px_bytes;
+    const unsigned row_bytes = lay.row_bytes;
 
-    const int b = lane & (kBinsPerIter - 1), q = lane >> 3;
-    const int ch = k * kChunk + q * 4;
-    const bool chok = ch < Cs;
+    // lane = q + 8*b: the 8 lanes that fetch the 8 channel quads of ONE pixel (one 128-byte
+    // line) are consecutive, so the texture addresser merges them into two 64-byte
+    // accesses.  (With the quads strided over the wave every lane costs its own access:
+    // measured 43 vs 16 TCP accesses per load instruction, TA busy 82 %.)
+    const unsigned q = lane & (kQuads - 1), b = lane >> 3;
+    // a channel quad wholly beyond C never loads (its rows are not stored either)
+    const unsigned q_bytes = (k * kChunk + q * 4 < (unsigned)C) ? q * 16u : kOOB;
+    // LDS tile: row r = channel, 68-dword pitch; the column of rows 8m..8m+7 is XORed with
+    // 4*m so that the 32 lanes of a store group (8 quads x 4 bins) hit 32 different banks
+    // while rows stay 16-byte aligned for the ds_read_b128 of phase C.
+    const unsigned wswz = (q >> 1) * 4u;  // rows 4q..4q+3 -> m = q >> 1
+    const unsigned col = (lane & 15) * 4, row0 = lane >> 4;
+    const unsigned chans_here = min((unsigned)kChunk, (unsigned)C - k * kChunk);  // rows of this chunk < C
+    const v4f z4 = {0.f, 0.f, 0.f, 0.f};
 
-    for (long item = slot; item < items; item += nslots) {
-        const int n = (int)(item / ntiles);
-        const int t = (int)(item - (long)n * ntiles);
+    // phase A of one item: lane = bin, geometry -> 32-byte tap record in LDS:
+    //   {off_lt, off_rt, off_lb, off_rb} byte offsets into the slice (kOOB = reads as 0.0),
+    //   {dx|dy flags, rx, ry, -}.
+    auto geometry = [&](const Affine& A, unsigned t) {
+        const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
+        const unsigned bin = t * kTileBins + lane;
+        const unsigned ph = fdiv(bin, div_pw);
+        const unsigned pw = bin - ph * (unsigned)pooled_width;
+        float bcx, bcy;
+        bool active = bin_centre(A, (int)ph, (int)pw, height, width, bcx, bcy);
+        active = active && bin < (unsigned)NB && batch_ok;
+        const float fx = floorf(bcx), fy = floorf(bcy);
+        const int x0 = f2i_sat(fx), x1 = f2i_sat(ceilf(bcx));
+        const int y0 = f2i_sat(fy), y1 = f2i_sat(ceilf(bcy));
+        const bool x0ok = x0 > 0 && x0 < width, x1ok = x1 > 0 && x1 < width;
+        const bool y0ok = y0 > 0 && y0 < height, y1ok = y1 > 0 && y1 < height;
+        const bool dx = active && x1 != x0, dy = active && y1 != y0;
+        // kernel.cu:116-126 validity; a tap that aliases lt (dx == 0 / dy == 0) is not loaded
+        const bool l00 = active && y0ok && x0ok;
+        const bool l01 = dx && y0ok && x1ok;
+        const bool l10 = dy && y1ok && x0ok;
+        const bool l11 = dx && dy && y1ok && x1ok;
+        const unsigned o00 = (unsigned)y0 * row_bytes + (unsigned)x0 * px_bytes;
+        uint4 ra;
+        ra.x = l00 ? o00 : kOOB;
+        ra.y = l01 ? o00 + px_bytes : kOOB;
+        ra.z = l10 ? o00 + row_bytes : kOOB;
+        ra.w = l11 ? o00 + row_bytes + px_bytes : kOOB;
+        // a masked bin blends four zeros; give it clean weights (its centre may be NaN)
+        const float rx = active ? bcx - fx : 0.0f;
+        const float ry = active ? bcy - fy : 0.0f;
+        G[2 * lane + 0] = ra;
+        G[2 * lane + 1] = make_uint4((dx ? kDx : 0u) | (dy ? kDy : 0u), as_u(rx), as_u(ry), 0u);
+    };
+    auto slice_rsrc = [&](const Affine& A) {
+        const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
+        const float* base = map + (size_t)(batch_ok ? A.batch : 0) * lay.img_stride + (size_t)k * lay.chunk_stride;
+        return make_rsrc(base, lay.slice_bytes);
+    };
 
-        // ---- phase A: lane = bin; geometry -> LDS record -----------------------------
-        const Affine A = aff[n];
-        {
-            const int bin = t * kTileBins + lane;
-            const int ph = bin / pooled_width;
-            const int pw = bin - ph * pooled_width;
-            float bcx, bcy;
-            bool active = bin_centre(A, ph, pw, height, width, bcx, bcy);
-            active = active && bin < NB && A.batch >= 0 && A.batch < batch_size;
-            const Taps tp = make_taps(bcx, bcy, active, height, width, pixel_stride);
-            G[lane] = make_uint4(tp.o_lt, tp.flags, as_u(tp.rx), as_u(tp.ry));
-        }
-        __syncthreads();
+    uint4 ra[2], rb[2];
+    v4f lt[2], rt[2], lb[2], rbv[2];
+    auto fetch = [&](int it, int s) {
+        ra[s] = G[2 * (it * kBinsPerIter + b) + 0];
+        rb[s] = G[2 * (it * kBinsPerIter + b) + 1];
+    };
+    auto issue = [&](__amdgpu_buffer_rsrc_t rs, int s) {
+        // kOOB + q_bytes (or anything + kOOB) stays out of range: no wrap below 2^32
+        lt[s] = buf_load(rs, ra[s].x + q_bytes);
+        rt[s] = buf_load(rs, ra[s].y + q_bytes);
+        lb[s] = buf_load(rs, ra[s].z + q_bytes);
+        rbv[s] = buf_load(rs, ra[s].w + q_bytes);
+    };
 
-        // ---- phase B: lane = (bin b of 8, channel quad q of 8); gather + blend --------
-        const int batch = (A.batch >= 0 && A.batch < batch_size) ? A.batch : 0;
-        const float* sp = pm + (size_t)batch * height * width * Cs + ch;
+    // The item loop is software-pipelined ACROSS items: while item i is blended and
+    // streamed out, the affine of item i+1 is already loaded, its records are built as
+    // soon as item i has fetched its last record, and its first taps are in flight
+    // before item i's stores are issued.
+    unsigned item = slot;
+    if (item >= items) return;
+    unsigned n = fdiv(item, div_tiles);
+    unsigned t = item - n * (unsigned)ntiles;
+    Affine A = aff[n];
+    geometry(A, t);
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t rs = slice_rsrc(A);
+    fetch(0, 0);
+    issue(rs, 0);
 
-        Taps g[kIters];
+    for (;;) {
+        const unsigned item_next = item + nslots;
+        const bool has_next = item_next < items;
+        const unsigned n_next = has_next ? fdiv(item_next, div_tiles) : n;
+        const unsigned t_next = item_next - n_next * (unsigned)ntiles;
+        const Affine A_next = aff[n_next];  // in flight during phase B
+
+        // ---- phase B of the current item -------------------------------------------------
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
-            const uint4 u = G[it * kBinsPerIter + b];
-            g[it].o_lt = u.x;
-            g[it].flags = u.y;
-            g[it].rx = as_f(u.z);
-            g[it].ry = as_f(u.w);
-        }
-        TapRegs cur = load_taps(sp, g[0], pixel_stride, row_stride, chok);
-#pragma unroll
-        for (int it = 0; it < kIters; ++it) {
-            TapRegs nxt;
-            if (it + 1 < kIters) nxt = load_taps(sp, g[it + 1], pixel_stride, row_stride, chok);
-            alias_taps(cur, g[it].flags);
+            const int s = it & 1;
+            if (it + 1 < kIters) {
+                fetch(it + 1, s ^ 1);
+                issue(rs, s ^ 1);
+            }
+            const unsigned f = rb[s].x;
+            const bool dx = f & kDx, dy = f & kDy;
+            // kernel.cu:110-126 read the same pixel again when floor == ceil
+            const v4f t_lt = lt[s];
+            const v4f t_rt = dx ? rt[s] : t_lt;
+            const v4f t_lb = dy ? lb[s] : t_lt;
+            const v4f t_rb = dx ? (dy ? rbv[s] : t_rt) : t_lb;
             float wlt, wrt, wrb, wlb;
-            tap_weights(g[it].rx, g[it].ry, wlt, wrt, wrb, wlb);
-            const bool act = g[it].flags & kActive;
-            const float v0 = act ? blend1(cur.lt.x, cur.rt.x, cur.rb.x, cur.lb.x, wlt, wrt, wrb, wlb) : 0.0f;
-            const float v1 = act ? blend1(cur.lt.y, cur.rt.y, cur.rb.y, cur.lb.y, wlt, wrt, wrb, wlb) : 0.0f;
-            const float v2 = act ? blend1(cur.lt.z, cur.rt.z, cur.rb.z, cur.lb.z, wlt, wrt, wrb, wlb) : 0.0f;
-            const float v3 = act ? blend1(cur.lt.w, cur.rt.w, cur.rb.w, cur.lb.w, wlt, wrt, wrb, wlb) : 0.0f;
-            float* tw = T + (q * 4) * kTStride + it * kBinsPerIter + b;
-            tw[0 * kTStride] = v0;
-            tw[1 * kTStride] = v1;
-            tw[2 * kTStride] = v2;
-            tw[3 * kTStride] = v3;
-            if (it + 1 < kIters) cur = nxt;
+            tap_weights(as_f(rb[s].y), as_f(rb[s].z), wlt, wrt, wrb, wlb);
+            v4f v = z4;  // kernel.cu:136-141, four channels at a time
+            v += t_lt * wlt;
+            v += t_rt * wrt;
+            v += t_rb * wrb;
+            v += t_lb * wlb;
+            float* tw = T + (q * 4) * kTStride + ((it * kBinsPerIter + b) ^ wswz);
+            tw[0 * kTStride] = v.x;
+            tw[1 * kTStride] = v.y;
+            tw[2 * kTStride] = v.z;
+            tw[3 * kTStride] = v.w;
+        }
+        // every record of this item has been fetched: G is free for the next item
+        __amdgpu_buffer_rsrc_t rs_next = rs;
+        if (has_next) {
+            geometry(A_next, t_next);
+            rs_next = slice_rsrc(A_next);
         }
         __syncthreads();
+        if (has_next) {
+            fetch(0, 0);
+            issue(rs_next, 0);
+        }
 
-        // ---- phase C: lane = (row r of 4, 4 consecutive bins); stream the tile out ----
-        const int col = (lane & 15) * 4;
-        const int bin0 = t * kTileBins + col;
+        // ---- phase C of the current item: [rows < C] x [64 bins] -> 256-byte row segments ----
+        {
+            // descriptor over this (roi, chunk) block of the output: rows >= C fall out of range
+            float* obase = out + ((size_t)n * C + k * kChunk) * NB;
+            const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, chans_here * (unsigned)NB * 4u);
+            const unsigned bin0 = t * kTileBins + col;
+            v4f v[kChunk / 4];
 #pragma unroll
-        for (int s = 0; s < kChunk / 4; ++s) {
-            const int r = s * 4 + (lane >> 4);
-            const int c = k * kChunk + r;
-            const float4 v = *reinterpret_cast<const float4*>(T + r * kTStride + col);
-            if (c < C) {
-                float* op = out + ((size_t)n * C + c) * NB + bin0;
-                if (VEC_STORE) {
-                    // NB % 4 == 0: the 4 bins are all inside or all outside the row, 16 B aligned
-                    if (bin0 < NB) st4_nt(op, v);
+            for (int s = 0; s < kChunk / 4; ++s) {
+                const unsigned r = s * 4 + row0;
+                v[s] = *reinterpret_cast<const v4f*>(T + r * kTStride + (col ^ ((r >> 3) * 4u)));
+            }
+#pragma unroll
+            for (int s = 0; s < kChunk / 4; ++s) {
+                const unsigned r = s * 4 + row0;
+                const unsigned off = (r * (unsigned)NB + bin0) * 4u;
+                if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
+                    buf_store<AUX>(ws, bin0 < (unsigned)NB ? off : kOOB, v[s]);
                 } else {
-                    if (bin0 + 0 < NB) __builtin_nontemporal_store(v.x, op + 0);
-                    if (bin0 + 1 < NB) __builtin_nontemporal_store(v.y, op + 1);
-                    if (bin0 + 2 < NB) __builtin_nontemporal_store(v.z, op + 2);
-                    if (bin0 + 3 < NB) __builtin_nontemporal_store(v.w, op + 3);
+                    buf_store1<AUX>(ws, bin0 + 0 < (unsigned)NB ? off + 0 : kOOB, v[s].x);
+                    buf_store1<AUX>(ws, bin0 + 1 < (unsigned)NB ? off + 4 : kOOB, v[s].y);
+                    buf_store1<AUX>(ws, bin0 + 2 < (unsigned)NB ? off + 8 : kOOB, v[s].z);
+                    buf_store1<AUX>(ws, bin0 + 3 < (unsigned)NB ? off + 12 : kOOB, v[s].w);
                 }
             }
         }
         __syncthreads();
+        if (!has_next) break;
+        item = item_next;
+        n = n_next;
+        t = t_next;
+        A = A_next;
+        rs = rs_next;
     }
 }
 
@@ -447,89 +575,94 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// Backward, tiled: scatter into a pixel-major gradient (B, H*W, Cs) with hardware
-// fp32 atomics (lanes of a wave hit consecutive channels of a pixel, so an
-// atomic instruction touches whole lines, and with the XCD mapping all atomics
-// of a channel chunk resolve in one L2), then relayout to NCHW.
+// Backward, tiled: scatter into a chunk-major gradient (B, C/32, H*W, 32), zeroed,
+// with hardware fp32 atomics: 8 lanes x 4 channels cover one 128-byte line of a
+// pixel, all atomics of chunk k resolve in the L2 of the XCD that owns k; then
+// relayout to NCHW.  Same item decomposition as the forward.
 // ------------------------------------------------------------------------------------
 template <bool VEC_LOAD>
 __global__ __launch_bounds__(kWave) void rroi_bwd_tiled_kernel(
-    const float* __restrict__ top_diff,  // (R, C, PH*PW)
-    const Affine* __restrict__ aff, float* __restrict__ gpm,  // (B, H*W, Cs) zeroed
-    int num_rois, int C, int Cs, int height, int width, int pooled_height, int pooled_width,
-    int batch_size, int nchunks, int ntiles)
+    const float* __restrict__ top_diff, const Affine* __restrict__ aff, float* __restrict__ gcm,
+    int num_rois, int C, int height, int width, int pitch, int pooled_width, int NB, int batch_size,
+    int nchunks, int ntiles, FastDiv div_tiles, FastDiv div_pw)
 {
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride];
     __shared__ __attribute__((aligned(16))) uint4 G[kTileBins];
 
-    const int lane = threadIdx.x;
-    const int k = blockIdx.x % nchunks;
-    const int slot = blockIdx.x / nchunks;
-    const int nslots = gridDim.x / nchunks;
-    const int NB = pooled_height * pooled_width;
-    const long items = (long)num_rois * ntiles;
-    const unsigned pixel_stride = (unsigned)Cs;
-    const unsigned row_stride = (unsigned)width * (unsigned)Cs;
-    const int b = lane & (kBinsPerIter - 1), q = lane >> 3;
-    const int ch = k * kChunk + q * 4;
+    const unsigned lane = threadIdx.x;
+    const unsigned k = blockIdx.x % (unsigned)nchunks;
+    const unsigned slot = blockIdx.x / (unsigned)nchunks;
+    const unsigned nslots = gridDim.x / (unsigned)nchunks;
+    const unsigned items = (unsigned)num_rois * (unsigned)ntiles;
+    const unsigned slice_px = (unsigned)height * (unsigned)pitch;
+    const unsigned q = lane & (kQuads - 1), b = lane >> 3;  // as in the forward: a pixel's quads are adjacent lanes
+    const unsigned wswz = (q >> 1) * 4u;
+    const unsigned col = (lane & 15) * 4, row0 = lane >> 4;
+    const unsigned cvalid = (unsigned)C - min((unsigned)C, k * kChunk + q * 4);  // channels of this quad < C
 
-    for (long item = slot; item < items; item += nslots) {
-        const int n = (int)(item / ntiles);
-        const int t = (int)(item - (long)n * ntiles);
+    for (unsigned item = slot; item < items; item += nslots) {
+        const unsigned n = fdiv(item, div_tiles);
+        const unsigned t = item - n * (unsigned)ntiles;
         const Affine A = aff[n];
+        const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
         {
-            const int bin = t * kTileBins + lane;
-            const int ph = bin / pooled_width;
-            const int pw = bin - ph * pooled_width;
+            const unsigned bin = t * kTileBins + lane;
+            const unsigned ph = fdiv(bin, div_pw);
+            const unsigned pw = bin - ph * (unsigned)pooled_width;
             float bcx, bcy;
             // kernel.cu:232-242: the backward reads the centre the forward stored; where the
             // forward's mask (pw <= roi_pooled_width) was false it stored nothing, the
             // buffer holds 0, and a (0,0) centre fails every bound of :267-274.  So the
             // scatter happens exactly where the forward's mask holds.
-            bool active = bin_centre(A, ph, pw, height, width, bcx, bcy);
-            active = active && bin < NB && A.batch >= 0 && A.batch < batch_size;
-            const Taps tp = make_taps(bcx, bcy, active, height, width, pixel_stride);
+            bool active = bin_centre(A, (int)ph, (int)pw, height, width, bcx, bcy);
+            active = active && bin < (unsigned)NB && batch_ok;
+            Taps tp = make_taps(bcx, bcy, active, height, width, kChunk);
+            // re-base the first tap on the padded row pitch of the chunk-major gradient
+            {
+                const int x0 = f2i_sat(floorf(bcx)), y0 = f2i_sat(floorf(bcy));
+                tp.o_lt = ((unsigned)y0 * (unsigned)pitch + (unsigned)x0) * kChunk;
+            }
             G[lane] = make_uint4(tp.o_lt, tp.flags, as_u(tp.rx), as_u(tp.ry));
         }
         // stage the [32 ch][64 bin] slice of top_diff
-        const int col = (lane & 15) * 4;
-        const int bin0 = t * kTileBins + col;
+        {
+            const float* ibase = top_diff + ((size_t)n * C + k * kChunk) * NB + (size_t)t * kTileBins;
+            const unsigned bin0 = t * kTileBins + col;
 #pragma unroll
-        for (int s = 0; s < kChunk / 4; ++s) {
-            const int r = s * 4 + (lane >> 4);
-            const int c = k * kChunk + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < C) {
-                const float* ip = top_diff + ((size_t)n * C + c) * NB + bin0;
-                if (VEC_LOAD) {
-                    if (bin0 < NB) v = ld4_nt(ip);
-                } else {
-                    if (bin0 + 0 < NB) v.x = ip[0];
-                    if (bin0 + 1 < NB) v.y = ip[1];
-                    if (bin0 + 2 < NB) v.z = ip[2];
-                    if (bin0 + 3 < NB) v.w = ip[3];
+            for (int s = 0; s < kChunk / 4; ++s) {
+                const unsigned r = s * 4 + row0;
+                v4f v = {0.f, 0.f, 0.f, 0.f};
+                if (k * kChunk + r < (unsigned)C) {
+                    const float* ip = ibase + (size_t)(r * (unsigned)NB + col);
+                    if (VEC_LOAD) {
+                        if (bin0 < (unsigned)NB) v = *reinterpret_cast<const v4f*>(ip);
+                    } else {
+                        if (bin0 + 0 < (unsigned)NB) v.x = ip[0];
+                        if (bin0 + 1 < (unsigned)NB) v.y = ip[1];
+                        if (bin0 + 2 < (unsigned)NB) v.z = ip[2];
+                        if (bin0 + 3 < (unsigned)NB) v.w = ip[3];
+                    }
                 }
+                *reinterpret_cast<v4f*>(T + r * kTStride + (col ^ ((r >> 3) * 4u))) = v;
             }
-            *reinterpret_cast<float4*>(T + r * kTStride + col) = v;
         }
         __syncthreads();
 
-        const int batch = (A.batch >= 0 && A.batch < batch_size) ? A.batch : 0;
-        float* gp = gpm + (size_t)batch * height * width * Cs + ch;
+        float* gp = gcm + ((size_t)(batch_ok ? A.batch : 0) * nchunks + k) * ((size_t)slice_px * kChunk) + q * 4;
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
             const uint4 u = G[it * kBinsPerIter + b];
             const unsigned f = u.y;
             float wlt, wrt, wrb, wlb;
             tap_weights(as_f(u.z), as_f(u.w), wlt, wrt, wrb, wlb);
-            const float* tr = T + (q * 4) * kTStride + it * kBinsPerIter + b;
+            const float* tr = T + (q * 4) * kTStride + ((it * kBinsPerIter + b) ^ wswz);
             const unsigned o_lt = u.x;
-            const unsigned o_rt = o_lt + ((f & kDx) ? pixel_stride : 0u);
-            const unsigned o_lb = o_lt + ((f & kDy) ? row_stride : 0u);
-            const unsigned o_rb = o_lb + ((f & kDx) ? pixel_stride : 0u);
+            const unsigned o_rt = o_lt + ((f & kDx) ? (unsigned)kChunk : 0u);
+            const unsigned o_lb = o_lt + ((f & kDy) ? (unsigned)pitch * kChunk : 0u);
+            const unsigned o_rb = o_lb + ((f & kDx) ? (unsigned)kChunk : 0u);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (ch + j >= C) break;
+                if ((unsigned)j >= cvalid) break;
                 const float gval = tr[j * kTStride];
                 // kernel.cu:260-274: v1..v4 = w * top_diff, four independent atomicAdds
                 if (f & kB00) unsafeAtomicAdd(gp + o_lt + j, wlt * gval);
@@ -542,35 +675,47 @@ __global__ __launch_bounds__(kWave) void rroi_bwd_tiled_kernel(
     }
 }
 
-// pixel-major (B, H*W, Cs) -> NCHW (B, C, H*W); inverse of the prologue's relayout.
-__global__ __launch_bounds__(256) void rroi_pm_to_nchw_kernel(const float* __restrict__ pm,
+// chunk-major gradient (B, nchunks, HW, 32) -> NCHW (B, C, HW); inverse of the prologue's tile.
+__global__ __launch_bounds__(256) void rroi_cm_to_nchw_kernel(const float* __restrict__ cm,
                                                               float* __restrict__ nchw, int C,
-                                                              int Cs, int HW, int ptiles,
-                                                              int ctiles)
+                                                              int HW, int width, int pitch,
+                                                              FastDiv div_w, int nchunks, int ptiles)
 {
-    __shared__ float T[64 * 65];
+    __shared__ float T[kChunk * (kRelayoutPx + 1)];
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
     const int pt = bid % ptiles;
     bid /= ptiles;
-    const int ct = bid % ctiles;
-    const int b = bid / ctiles;
+    const int k = bid % nchunks;
+    const int b = bid / nchunks;
     const int lane = tid & 63, w = tid >> 6;
-    const int p0 = pt * 64, c0 = ct * 64;
-    const float* src = pm + ((size_t)b * HW + p0) * Cs + c0;
+    const int p0 = pt * kRelayoutPx, c0 = k * kChunk;
+    const float* src = cm + ((size_t)b * nchunks + k) * ((size_t)(HW / width) * pitch * kChunk);
+    const int cq = lane & 7, pl = lane >> 3;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int p = w * 16 + i;
-        float v = 0.0f;
-        if (p0 + p < HW && c0 + lane < Cs) v = src[(size_t)p * Cs + lane];
-        T[lane * 65 + p] = v;
+    for (int j = 0; j < 4; ++j) {
+        const int p = w * 32 + j * 8 + pl;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        const unsigned gp = (unsigned)(p0 + p);
+        const unsigned y = fdiv(gp, div_w);
+        const size_t pix = (size_t)y * pitch + (gp - y * (unsigned)width);
+        if (p0 + p < HW) v = *reinterpret_cast<const v4f*>(src + pix * kChunk + cq * 4);
+        float* tw = T + (cq * 4) * (kRelayoutPx + 1) + p;
+        tw[0] = v.x;
+        tw[kRelayoutPx + 1] = v.y;
+        tw[2 * (kRelayoutPx + 1)] = v.z;
+        tw[3 * (kRelayoutPx + 1)] = v.w;
     }
     __syncthreads();
     float* dst = nchw + ((size_t)b * C + c0) * HW + p0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = w * 16 + i;
-        if (c0 + c < C && p0 + lane < HW) dst[(size_t)c * HW + lane] = T[c * 65 + lane];
+    for (int i = 0; i < 8; ++i) {
+        const int c = w * 8 + i;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int p = hlf * 64 + lane;
+            if (c0 + c < C && p0 + p < HW) dst[(size_t)c * HW + p] = T[c * (kRelayoutPx + 1) + p];
+        }
     }
 }
 
@@ -683,7 +828,6 @@ __global__ void rroi_sincos_probe_kernel(const float* __restrict__ deg, int n, f
 inline int status_of(hipError_t e) { return e == hipSuccess ? 1 : -(int)e; }
 inline int launch_status() { return status_of(hipGetLastError()); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-inline int round_up4(int c) { return (c + 3) & ~3; }
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 struct DeviceShape {
@@ -705,27 +849,46 @@ int num_cus()
     return g_dev.cus;
 }
 
+// Row pitch (pixels = 128-byte lines) of the chunk-major copy: W plus a pad that makes the
+// pitch odd, so that the lines of vertically adjacent pixels differ in their low address
+// bits and spread over the L2 channels.
+int g_row_pad = -1;  // exploration knob: -1 = automatic
+int row_pitch(int width)
+{
+    if (g_row_pad >= 0) return width + g_row_pad;
+    return width | 1;
+}
+
 bool shape_ok(int batch_size, int num_rois, int height, int width, int channels, int pooled_height,
               int pooled_width)
 {
     if (batch_size <= 0 || num_rois < 0 || height <= 0 || width <= 0 || channels <= 0 ||
         pooled_height <= 0 || pooled_width <= 0)
         return false;
-    // per-image pixel-major offsets are 32-bit; bins per roi are int
-    if ((long)height * width * round_up4(channels) >= (1L << 31)) return false;
+    // tap offsets inside a slice are 32-bit BYTE offsets; the image stride is a 32-bit float count
+    const long nchunks = (channels + kChunk - 1) / kChunk;
+    const long slice_px = (long)height * (width + 16) + 1;
+    if (slice_px * kLineBytes >= (1L << 31)) return false;                          // chunk-major (< kOOB)
+    if ((long)height * width * channels * 4 >= (1L << 31)) return false;            // channels-last
+    if ((long)kChunk * pooled_height * pooled_width * 4 >= (1L << 31)) return false; // one output block
+    if (slice_px * kChunk * nchunks >= (1L << 32)) return false;                    // img_stride
     if ((long)pooled_height * pooled_width >= (1L << 31)) return false;
     return true;
 }
 
-// grid for the tiled kernels: one wave per block, up to 16 waves per CU, a
-// multiple of lcm(nchunks, 8) so that blockIdx % nchunks is also stable per XCD.
+// grid for the tiled kernels: one wave per block, 12 waves per CU (measured optimum: LDS
+// admits 15, but beyond 12 the L1 hit rate of the tap loads drops faster than the extra
+// latency hiding pays), a multiple of lcm(nchunks, 8) so that blockIdx % nchunks is also
+// stable per XCD.
+int g_waves_per_cu = 12;
+
 int tiled_grid(long items, int nchunks)
 {
     long want = items * nchunks;
-    const long cap = (long)num_cus() * 16;
+    const long cap = (long)num_cus() * g_waves_per_cu;
     if (want > cap) want = cap;
     long unit = nchunks;
-    while (unit % 8) unit += nchunks;  // lcm(nchunks, 8) for nchunks <= ...; bounded by 8*nchunks
+    while (unit % 8) unit += nchunks;  // lcm(nchunks, 8)
     long g = (want + unit - 1) / unit * unit;
     if (g < nchunks) g = nchunks;
     return (int)g;
@@ -743,24 +906,38 @@ void direct_grid(int num_rois, int NB, int channels, dim3& grid, int& cslab)
     grid = dim3(bx, ceil_div(channels, cslab), 1);
 }
 
-struct FwdWorkspace {
+FastDiv make_fastdiv(unsigned d)
+{
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    FastDiv f;
+    f.m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+
+struct Workspace {
     Affine* aff;
-    float* pm;
+    float* cm;
+    size_t cm_bytes;
     size_t bytes;
 };
 
-FwdWorkspace carve_fwd(void* ws, int batch_size, int channels, int height, int width, int num_rois,
-                       int layout)
+// [affine table | chunk-major copy (B, nchunks, HW+1, 32)]; the copy is absent when
+// channels-last features with C % 4 == 0 are consumed in place.
+Workspace carve(void* ws, int batch_size, int channels, int height, int width, int num_rois,
+                int layout)
 {
-    FwdWorkspace w;
+    Workspace w;
     const size_t aff_bytes = align_up((size_t)(num_rois > 0 ? num_rois : 1) * sizeof(Affine), 256);
-    const size_t pm_bytes =
-        layout == RROI_LAYOUT_NHWC && channels % 4 == 0
-            ? 0
-            : align_up((size_t)batch_size * height * width * round_up4(channels) * sizeof(float), 256);
+    const size_t nchunks = (channels + kChunk - 1) / kChunk;
+    w.cm_bytes = layout == RROI_LAYOUT_NHWC
+                     ? 0
+                     : align_up((size_t)batch_size * nchunks * ((size_t)height * row_pitch(width) + 1) * kLineBytes, 256);
     w.aff = reinterpret_cast<Affine*>(ws);
-    w.pm = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + aff_bytes);
-    w.bytes = aff_bytes + pm_bytes;
+    w.cm = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + aff_bytes);
+    w.bytes = aff_bytes + w.cm_bytes;
     return w;
 }
 
@@ -774,25 +951,27 @@ bool pick_tiled(int batch_size, int channels, int height, int width, int num_roi
     return out_elems >= 2.0 * map_elems;
 }
 
+int g_store_aux = 16;  // exploration knob: cache policy of the output stores
+
 }  // namespace
 
 // ====================================================================================
 extern "C" {
 
-const char* rroi_align_hip_version(void) { return "rroi_align_hip 0.1.0 gfx950"; }
+const char* rroi_align_hip_version(void) { return "rroi_align_hip 0.2.0 gfx950"; }
 
 size_t rroi_align_forward_workspace_bytes(int batch_size, int channels, int height, int width,
                                           int num_rois, int feature_layout)
 {
     if (batch_size <= 0 || channels <= 0 || height <= 0 || width <= 0 || num_rois < 0) return 0;
-    return carve_fwd(nullptr, batch_size, channels, height, width, num_rois, feature_layout).bytes;
+    return carve(nullptr, batch_size, channels, height, width, num_rois, feature_layout).bytes;
 }
 
 size_t rroi_align_backward_workspace_bytes(int batch_size, int channels, int height, int width,
                                            int num_rois)
 {
     if (batch_size <= 0 || channels <= 0 || height <= 0 || width <= 0 || num_rois < 0) return 0;
-    return carve_fwd(nullptr, batch_size, channels, height, width, num_rois, RROI_LAYOUT_NCHW).bytes;
+    return carve(nullptr, batch_size, channels, height, width, num_rois, RROI_LAYOUT_NCHW).bytes;
 }
 
 int rroi_align_forward_hip(const float* features, int feature_layout, float spatial_scale,
@@ -842,49 +1021,79 @@ int rroi_align_forward_stages_hip(const float* features, int feature_layout, flo
         return launch_status();
     }
 
-    const FwdWorkspace ws =
-        carve_fwd(workspace, batch_size, channels, height, width, num_rois, feature_layout);
+    if (feature_layout == RROI_LAYOUT_NHWC && channels % 4 != 0) return 0;  // repack to NCHW first
+    const Workspace ws = carve(workspace, batch_size, channels, height, width, num_rois, feature_layout);
     if (!workspace || workspace_bytes < ws.bytes) return 0;
-    const int Cs = round_up4(channels);
     const int HW = height * width;
-    const bool zero_copy = feature_layout == RROI_LAYOUT_NHWC && channels % 4 == 0;
-    const float* pm = zero_copy ? features : ws.pm;
+    const int nchunks = ceil_div(channels, kChunk);
+    const bool zero_copy = feature_layout == RROI_LAYOUT_NHWC;
+    const float* map = zero_copy ? features : ws.cm;
+    const int pitch = row_pitch(width);
 
-    // prologue: relayout + affine table in one launch
+    // prologue: relayout + zero pixels + affine table in one launch
     if (stages & RROI_STAGE_PROLOGUE) {
-        const int ptiles = ceil_div(HW, 64), ctiles = ceil_div(Cs, 64);
-        int relayout_blocks = zero_copy ? 0 : ptiles * ctiles * batch_size;
+        const int ptiles = ceil_div(HW, kRelayoutPx);
+        const int relayout_blocks = zero_copy ? 0 : ptiles * nchunks * batch_size;
+        const int zero_blocks = zero_copy ? 0 : ceil_div((long)batch_size * nchunks * kChunk, 256);
         const int aff_blocks = ceil_div(num_rois, 256);
-        if (feature_layout == RROI_LAYOUT_NHWC && !zero_copy) {
-            // channels-last storage with C % 4 != 0: repack by treating it as a strided copy
-            // (rare: C = 3 image inputs).  Handled by a plain 2D memcpy.
-            hipError_t e = hipMemcpy2DAsync(ws.pm, (size_t)Cs * sizeof(float), features,
-                                            (size_t)channels * sizeof(float),
-                                            (size_t)channels * sizeof(float),
-                                            (size_t)batch_size * HW, hipMemcpyDeviceToDevice, stream);
-            if (e != hipSuccess) return status_of(e);
-            relayout_blocks = 0;
-        }
-        hipLaunchKernelGGL(rroi_prologue_kernel, dim3(relayout_blocks + aff_blocks), dim3(256), 0,
-                           stream, features, ws.pm, channels, Cs, HW, ptiles, ctiles,
-                           relayout_blocks, rois, num_rois, pooled_height, spatial_scale, ws.aff);
+        hipLaunchKernelGGL(rroi_prologue_kernel, dim3(relayout_blocks + zero_blocks + aff_blocks),
+                           dim3(256), 0, stream, features, ws.cm, channels, HW, width, pitch,
+                           make_fastdiv((unsigned)width), nchunks, ptiles, relayout_blocks,
+                           zero_blocks, batch_size, rois, num_rois, pooled_height, spatial_scale,
+                           ws.aff);
         const int st = launch_status();
         if (st != 1) return st;
     }
     if (stages & RROI_STAGE_GATHER) {
-        const int nchunks = ceil_div(channels, kChunk);
         const int ntiles = ceil_div(NB, kTileBins);
+        if ((long)num_rois * ntiles >= (1L << 31)) return 0;
         const int grid = tiled_grid((long)num_rois * ntiles, nchunks);
-        if (NB % 4 == 0)
-            hipLaunchKernelGGL(rroi_fwd_tiled_kernel<true>, dim3(grid), dim3(kWave), 0, stream, pm,
-                               ws.aff, top_data, num_rois, channels, Cs, height, width,
-                               pooled_height, pooled_width, batch_size, nchunks, ntiles);
-        else
-            hipLaunchKernelGGL(rroi_fwd_tiled_kernel<false>, dim3(grid), dim3(kWave), 0, stream, pm,
-                               ws.aff, top_data, num_rois, channels, Cs, height, width,
-                               pooled_height, pooled_width, batch_size, nchunks, ntiles);
+        SliceLayout lay;
+        if (zero_copy) {
+            lay.px_bytes = (unsigned)channels * 4u;
+            lay.row_bytes = (unsigned)width * lay.px_bytes;
+            lay.slice_bytes = (unsigned)HW * lay.px_bytes;  // to the end of the image (base = chunk k of pixel 0)
+            lay.chunk_stride = kChunk;
+            lay.img_stride = (unsigned)HW * (unsigned)channels;
+        } else {
+            lay.px_bytes = kLineBytes;
+            lay.row_bytes = (unsigned)pitch * kLineBytes;
+            lay.slice_bytes = (unsigned)height * lay.row_bytes;
+            lay.chunk_stride = ((unsigned)height * (unsigned)pitch + 1u) * kChunk;
+            lay.img_stride = lay.chunk_stride * (unsigned)nchunks;
+        }
+        const FastDiv dt = make_fastdiv((unsigned)ntiles), dp = make_fastdiv((unsigned)pooled_width);
+#define RROI_LAUNCH_FWD(VEC, AUX)                                                                    \
+    hipLaunchKernelGGL((rroi_fwd_tiled_kernel<VEC, AUX>), dim3(grid), dim3(kWave), 0, stream, map,   \
+                       ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,        \
+                       batch_size, nchunks, ntiles, lay, dt, dp)
+        if (NB % 4 != 0) RROI_LAUNCH_FWD(false, 16);
+        else if (g_store_aux == 0) RROI_LAUNCH_FWD(true, 0);   // exploration only
+        else if (g_store_aux == 2) RROI_LAUNCH_FWD(true, 2);   // exploration only
+        else RROI_LAUNCH_FWD(true, 16);
+#undef RROI_LAUNCH_FWD
     }
     return launch_status();
+}
+
+// exploration knobs (not part of the public ABI)
+int rroi_align_debug_set_store_aux(int v)
+{
+    const int old = g_store_aux;
+    g_store_aux = v;
+    return old;
+}
+int rroi_align_debug_set_row_pad(int v)
+{
+    const int old = g_row_pad;
+    g_row_pad = v;
+    return old;
+}
+int rroi_align_debug_set_waves_per_cu(int v)
+{
+    const int old = g_waves_per_cu;
+    if (v >= 1 && v <= 64) g_waves_per_cu = v;
+    return old;
 }
 
 int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batch_size,
@@ -919,32 +1128,34 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
         return launch_status();
     }
 
-    const FwdWorkspace ws =
-        carve_fwd(workspace, batch_size, channels, height, width, num_rois, RROI_LAYOUT_NCHW);
+    const Workspace ws = carve(workspace, batch_size, channels, height, width, num_rois, RROI_LAYOUT_NCHW);
     if (!workspace || workspace_bytes < ws.bytes) return 0;
-    const int Cs = round_up4(channels);
-    hipError_t e = hipMemsetAsync(ws.pm, 0, (size_t)batch_size * HW * Cs * sizeof(float), stream);
+    const int nchunks = ceil_div(channels, kChunk);
+    const int pitch = row_pitch(width);
+    hipError_t e = hipMemsetAsync(ws.cm, 0, (size_t)batch_size * nchunks * height * pitch * kLineBytes, stream);
     if (e != hipSuccess) return status_of(e);
     hipLaunchKernelGGL(rroi_affine_kernel, dim3(ceil_div(num_rois, 256)), dim3(256), 0, stream,
                        rois, num_rois, pooled_height, spatial_scale, ws.aff);
     int st = launch_status();
     if (st != 1) return st;
-    const int nchunks = ceil_div(channels, kChunk);
     const int ntiles = ceil_div(NB, kTileBins);
+    if ((long)num_rois * ntiles >= (1L << 31)) return 0;
     const int grid = tiled_grid((long)num_rois * ntiles, nchunks);
+    const FastDiv dt = make_fastdiv((unsigned)ntiles), dp = make_fastdiv((unsigned)pooled_width);
     if (NB % 4 == 0)
         hipLaunchKernelGGL(rroi_bwd_tiled_kernel<true>, dim3(grid), dim3(kWave), 0, stream,
-                           top_diff, ws.aff, ws.pm, num_rois, channels, Cs, height, width,
-                           pooled_height, pooled_width, batch_size, nchunks, ntiles);
+                           top_diff, ws.aff, ws.cm, num_rois, channels, height, width, pitch,
+                           pooled_width, NB, batch_size, nchunks, ntiles, dt, dp);
     else
         hipLaunchKernelGGL(rroi_bwd_tiled_kernel<false>, dim3(grid), dim3(kWave), 0, stream,
-                           top_diff, ws.aff, ws.pm, num_rois, channels, Cs, height, width,
-                           pooled_height, pooled_width, batch_size, nchunks, ntiles);
+                           top_diff, ws.aff, ws.cm, num_rois, channels, height, width, pitch,
+                           pooled_width, NB, batch_size, nchunks, ntiles, dt, dp);
     st = launch_status();
     if (st != 1) return st;
-    const int ptiles = ceil_div((long)HW, 64), ctiles = ceil_div(Cs, 64);
-    hipLaunchKernelGGL(rroi_pm_to_nchw_kernel, dim3(ptiles * ctiles * batch_size), dim3(256), 0,
-                       stream, ws.pm, bottom_diff, channels, Cs, (int)HW, ptiles, ctiles);
+    const int ptiles = ceil_div((long)HW, kRelayoutPx);
+    hipLaunchKernelGGL(rroi_cm_to_nchw_kernel, dim3(ptiles * nchunks * batch_size), dim3(256), 0,
+                       stream, ws.cm, bottom_diff, channels, (int)HW, width, pitch,
+                       make_fastdiv((unsigned)width), nchunks, ptiles);
     return launch_status();
 }
 

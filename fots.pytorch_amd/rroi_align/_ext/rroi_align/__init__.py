@@ -108,8 +108,8 @@ def forward(features: torch.Tensor, rois: torch.Tensor, pooled_height: int, pool
         raise ValueError("pooled_height and pooled_width must be positive")
     if features.is_contiguous():
         layout = LAYOUT_NCHW
-    elif features.is_contiguous(memory_format=torch.channels_last):
-        layout = LAYOUT_NHWC
+    elif features.is_contiguous(memory_format=torch.channels_last) and C % 4 == 0 and path != PATH_DIRECT:
+        layout = LAYOUT_NHWC  # consumed in place: a pixel's channels are already contiguous
     else:
         features, layout = features.contiguous(), LAYOUT_NCHW
     rois = rois.contiguous()

@@ -67,8 +67,8 @@ def stage(s, path=ext.PATH_TILED):
 
 
 res["fwd_prologue"] = timeit(lambda: stage(1))
-res["fwd_gather"] = timeit(lambda: stage(2))
-res["fwd_all"] = timeit(lambda: stage(3))
+res["fwd_gather"] = timeit(lambda: stage(2), iters=100)
+res["fwd_all"] = timeit(lambda: stage(3), iters=100)
 res["fwd_direct"] = timeit(lambda: stage(2, ext.PATH_DIRECT), iters=20)
 ours = out.clone()
 

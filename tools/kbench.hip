@@ -1,0 +1,424 @@
+// tools/kbench.hip -- standalone micro-benchmarks for the RoIRotate forward on MI355X.
+// Measurement tooling (not product, not shipped): includes the product translation unit to
+// reuse its device code, adds ablation kernels, times everything with hipEvents.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -o tools/kbench tools/kbench.hip
+#include "../fots.pytorch_amd/csrc/rroi_align_hip.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+#include <vector>
+
+#define CK(x)                                                                         \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            exit(1);                                                                  \
+        }                                                                             \
+    } while (0)
+
+namespace {
+
+constexpr int R = 512, C = 256, H = 160, W = 160, PH = 8, PW = 64, NB = PH * PW;
+
+// ---- store-only: the product's tile pattern (256 B row segments, 2 KiB apart) -------------
+template <int MODE>  // 0 = nontemporal, 1 = plain, 2 = sc1-ish (agent-scope relaxed atomic store path n/a)
+__global__ __launch_bounds__(64) void k_store_tile(float* __restrict__ out, int nchunks, int ntiles)
+{
+    const unsigned lane = threadIdx.x;
+    const unsigned k = blockIdx.x % nchunks, slot = blockIdx.x / nchunks, nslots = gridDim.x / nchunks;
+    const unsigned items = R * ntiles;
+    const unsigned col = (lane & 15) * 4, row0 = lane >> 4;
+    const v4f v = {1.f, 2.f, 3.f, (float)lane};
+    for (unsigned item = slot; item < items; item += nslots) {
+        const unsigned n = item / ntiles, t = item % ntiles;
+        float* obase = out + ((size_t)n * C + k * 32) * NB + (size_t)t * 64;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const unsigned r = s * 4 + row0;
+            float* op = obase + (size_t)(r * NB + col);
+            if (MODE == 0) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(op));
+            else *reinterpret_cast<v4f*>(op) = v;
+        }
+    }
+}
+
+// ---- store-only: fully linear, every wave writes contiguous 8 KiB pieces -------------------
+template <int MODE>
+__global__ __launch_bounds__(64) void k_store_linear(float* __restrict__ out, unsigned pieces)
+{
+    const unsigned lane = threadIdx.x;
+    const v4f v = {1.f, 2.f, 3.f, (float)lane};
+    for (unsigned p = blockIdx.x; p < pieces; p += gridDim.x) {
+        float* base = out + (size_t)p * 2048 + lane * 4;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (MODE == 0) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(base + s * 256));
+            else *reinterpret_cast<v4f*>(base + s * 256) = v;
+        }
+    }
+}
+
+// ---- store-only with 256-thread blocks, linear (what a tuned fill looks like) --------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_store_linear256(float* __restrict__ out, size_t n4)
+{
+    const v4f v = {1.f, 2.f, 3.f, 4.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        if (MODE == 0) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(out) + i);
+        else reinterpret_cast<v4f*>(out)[i] = v;
+    }
+}
+
+// ---- gather-only: product phase A+B, the tile is reduced instead of stored ------------------
+__global__ __launch_bounds__(64) void k_gather_only(const float* __restrict__ pm, const Affine* __restrict__ aff,
+                                                   float* __restrict__ sink, int nchunks, int ntiles,
+                                                   unsigned img_stride, FastDiv div_tiles, FastDiv div_pw,
+                                                   int all_taps, int pitch)
+{
+    __shared__ __attribute__((aligned(16))) uint4 G[64 * 2];
+    const unsigned lane = threadIdx.x;
+    const unsigned k = blockIdx.x % nchunks, slot = blockIdx.x / nchunks, nslots = gridDim.x / nchunks;
+    const unsigned items = R * ntiles;
+    const unsigned px_bytes = 128u, zp_bytes = H * pitch * px_bytes;
+    const unsigned q = lane & 7, b = lane >> 3;
+    const unsigned ch_bytes = q * 16u;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned item = slot; item < items; item += nslots) {
+        const unsigned n = fdiv(item, div_tiles);
+        const unsigned t = item - n * ntiles;
+        const Affine A = aff[n];
+        {
+            const unsigned bin = t * 64 + lane;
+            const unsigned ph = fdiv(bin, div_pw), pw = bin - ph * PW;
+            float bcx, bcy;
+            bool active = bin_centre(A, ph, pw, H, W, bcx, bcy);
+            const float fx = floorf(bcx), fy = floorf(bcy);
+            const int x0 = f2i_sat(fx), x1 = f2i_sat(ceilf(bcx)), y0 = f2i_sat(fy), y1 = f2i_sat(ceilf(bcy));
+            const bool x0ok = x0 > 0 && x0 < W, x1ok = x1 > 0 && x1 < W, y0ok = y0 > 0 && y0 < H, y1ok = y1 > 0 && y1 < H;
+            const bool dx = active && x1 != x0, dy = active && y1 != y0;
+            const unsigned o00 = ((unsigned)y0 * pitch + (unsigned)x0) * px_bytes, rowb = pitch * px_bytes;
+            uint4 ra;
+            ra.x = active && y0ok && x0ok ? o00 : zp_bytes;
+            ra.y = active && y0ok && x1ok ? o00 + px_bytes : zp_bytes;
+            ra.z = active && y1ok && x0ok ? o00 + rowb : zp_bytes;
+            ra.w = active && y1ok && x1ok ? o00 + rowb + px_bytes : zp_bytes;
+            unsigned f = (active && y0ok && x0ok ? kL0 : 0) | (dx && y0ok && x1ok ? kL1 : 0u) |
+                         (dy && y1ok && x0ok ? kL2 : 0u) | (dx && dy && y1ok && x1ok ? kL3 : 0u);
+            if (all_taps) f = kL0 | kL1 | kL2 | kL3;
+            G[2 * lane] = ra;
+            G[2 * lane + 1] = make_uint4(f, 0, 0, 0);
+        }
+        __syncthreads();
+        const char* base = reinterpret_cast<const char*>(pm + (size_t)k * img_stride);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const uint4 ra = G[2 * (it * 8 + b)];
+            const unsigned f = G[2 * (it * 8 + b) + 1].x;
+            v4f a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+            if (f & kL0) a0 = *reinterpret_cast<const v4f*>(base + (size_t)(ra.x + ch_bytes));
+            if (f & kL1) a1 = *reinterpret_cast<const v4f*>(base + (size_t)(ra.y + ch_bytes));
+            if (f & kL2) a2 = *reinterpret_cast<const v4f*>(base + (size_t)(ra.z + ch_bytes));
+            if (f & kL3) a3 = *reinterpret_cast<const v4f*>(base + (size_t)(ra.w + ch_bytes));
+            acc += (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+    }
+    if (acc.x == 12345.678f) sink[blockIdx.x * 64 + lane] = acc.x + acc.y + acc.z + acc.w;
+}
+
+// ---- raw L2->CU gather bandwidth: every lane group of LPG lanes reads one contiguous run of
+// LPG*16 bytes at a pseudo-random offset inside `region_bytes`; DEPTH independent loads in
+// flight per wave.  LPG = 64: 1 KiB contiguous per instruction; 8: eight 128 B lines; 1: 64 x 16 B.
+template <int LPG, int DEPTH>
+__global__ __launch_bounds__(64) void k_l2_gather(const char* __restrict__ src0, unsigned region_bytes,
+                                                 int iters, float* __restrict__ sink, int slice_mode = 0)
+{
+    const unsigned lane = threadIdx.x;
+    const unsigned slice = slice_mode == 1 ? blockIdx.x % 8 : slice_mode == 2 ? (blockIdx.x / 8) % 8 : 0;
+    const char* src = src0 + (size_t)slice * region_bytes;
+    const unsigned grp = lane / LPG, sub = lane % LPG;
+    const unsigned run = LPG * 16u;
+    const unsigned nruns = region_bytes / run;
+    unsigned state = (blockIdx.x * 64u + grp) * 2654435761u + 12345u;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < iters; ++i) {
+        v4f v[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            state = state * 1664525u + 1013904223u;
+            const unsigned r = (unsigned)(((unsigned long long)(state >> 8) * nruns) >> 24);
+            v[d] = *reinterpret_cast<const v4f*>(src + (size_t)r * run + sub * 16u);
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) acc += v[d];
+    }
+    if (acc.x == 12345.678f) sink[blockIdx.x * 64 + lane] = acc.x + acc.y + acc.z + acc.w;
+}
+
+// ---- store-only, product tile pattern, buffer_store with cache-policy bits AUX (gfx940 family:
+// 1 = sc0, 2 = nt, 16 = sc1) --------------------------------------------------------------
+template <int AUX>
+__global__ __launch_bounds__(64) void k_store_aux(float* __restrict__ out, int nchunks, int ntiles)
+{
+    const unsigned lane = threadIdx.x;
+    const unsigned k = blockIdx.x % nchunks, slot = blockIdx.x / nchunks, nslots = gridDim.x / nchunks;
+    const unsigned items = R * ntiles;
+    const unsigned col = (lane & 15) * 4, row0 = lane >> 4;
+    const v4u v = {1u, 2u, 3u, lane};
+    for (unsigned item = slot; item < items; item += nslots) {
+        const unsigned n = item / ntiles, t = item % ntiles;
+        float* obase = out + ((size_t)n * C + k * 32) * NB;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, 32u * NB * 4u);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const unsigned r = s * 4 + row0;
+            __builtin_amdgcn_raw_buffer_store_b128(v, ws, (r * NB + t * 64 + col) * 4u, 0, AUX);
+        }
+    }
+}
+
+// ---- TA instruction rate: buffer_load_dwordx4 in a 16 KiB (L1-resident) window; a fraction of
+// the 8-lane groups is out of range (MODE 0: none, 1: half, 2: 7/8, 3: all) or exec-masked
+// (MODE 4: half masked by a branch). 8 independent loads in flight.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_ta_rate(const float* __restrict__ src, int iters, float* __restrict__ sink)
+{
+    const unsigned lane = threadIdx.x, grp = lane >> 3;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, 16384u);
+    bool oob = false;
+    if (MODE == 1) oob = grp & 1;
+    if (MODE == 2) oob = grp != 0;
+    if (MODE == 3) oob = true;
+    const unsigned off0 = oob ? kOOB : lane * 16u;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < iters; ++i) {
+        v4f v[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const unsigned off = off0 + (unsigned)(((i * 8 + d) * 1024) & 15360);
+            if (MODE == 4) {
+                v[d] = acc;
+                if (grp & 1) v[d] = buf_load(rs, off);
+            } else {
+                v[d] = buf_load(rs, off);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) acc += v[d];
+    }
+    if (acc.x == 12345.678f) sink[blockIdx.x * 64 + lane] = acc.x + acc.y + acc.z + acc.w;
+}
+
+struct Timer {
+    hipEvent_t a, b;
+    Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
+    template <class F>
+    double us(F&& f, int iters = 50, int warm = 5)
+    {
+        for (int i = 0; i < warm; ++i) f();
+        CK(hipDeviceSynchronize());
+        std::vector<float> t(iters);
+        for (int i = 0; i < iters; ++i) {
+            CK(hipEventRecord(a));
+            f();
+            CK(hipEventRecord(b));
+            CK(hipEventSynchronize(b));
+            CK(hipEventElapsedTime(&t[i], a, b));
+        }
+        std::sort(t.begin(), t.end());
+        return t[iters / 2] * 1e3;
+    }
+};
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    const size_t out_elems = (size_t)R * C * NB;
+    float *feat, *out, *rois_d, *sink;
+    void* ws;
+    const size_t wsb = rroi_align_forward_workspace_bytes(1, C, H, W, R, 0) + (8u << 20);
+    CK(hipMalloc(&feat, (size_t)C * H * W * 4));
+    CK(hipMalloc(&out, out_elems * 4));
+    CK(hipMalloc(&rois_d, R * 24));
+    CK(hipMalloc(&ws, wsb));
+    CK(hipMalloc(&sink, 1 << 22));
+    std::mt19937 rng(0);
+    std::uniform_real_distribution<float> U(0.f, 1.f);
+    std::vector<float> hf((size_t)C * H * W), hr(R * 6);
+    for (auto& x : hf) x = U(rng) - 0.5f;
+    for (int i = 0; i < R; ++i) {
+        const float h = 16 + 48 * U(rng);
+        hr[i * 6 + 0] = 0;
+        hr[i * 6 + 1] = 640 * U(rng);
+        hr[i * 6 + 2] = 640 * U(rng);
+        hr[i * 6 + 3] = h;
+        hr[i * 6 + 4] = h * (4 + 4 * U(rng));
+        hr[i * 6 + 5] = -90 + 180 * U(rng);
+    }
+    CK(hipMemcpy(feat, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(rois_d, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
+    Timer T;
+    const double MB = out_elems * 4 / 1e6;
+    auto report = [&](const char* name, double us, double mb) {
+        printf("%-44s %9.2f us  %8.1f GB/s\n", name, us, mb / us * 1e3);
+        fflush(stdout);
+    };
+
+    if (argc > 1 && std::string(argv[1]) == "pmc") {
+        // short list for counter collection: each kernel a few times, no timing loops
+        auto stage = [&](int s) {
+            int rc = rroi_align_forward_stages_hip(feat, 0, 0.25f, 1, R, H, W, C, PH, PW, rois_d, out, ws, wsb, 2, s, 0);
+            if (rc != 1) { fprintf(stderr, "stage rc=%d\n", rc); exit(1); }
+        };
+        const Workspace w = carve(ws, 1, C, H, W, R, 0);
+        const FastDiv dt = make_fastdiv(8), dp = make_fastdiv(PW);
+        const int pitch = row_pitch(W);
+        for (int rep = 0; rep < 3; ++rep) {
+            stage(1);
+            stage(2);
+            if (argc > 2) continue;  // "pmc product": the product kernels only
+            hipLaunchKernelGGL(k_gather_only, dim3(4096), dim3(64), 0, 0, w.cm, w.aff, sink, 8, 8,
+                               (unsigned)(H * pitch + 1) * 32, dt, dp, 0, pitch);
+            hipLaunchKernelGGL(k_gather_only, dim3(4096), dim3(64), 0, 0, w.cm, w.aff, sink, 8, 8,
+                               (unsigned)(H * pitch + 1) * 32, dt, dp, 1, pitch);
+            hipLaunchKernelGGL((k_l2_gather<8, 4>), dim3(4096), dim3(64), 0, 0, (const char*)feat, 3u << 20, 64, sink, 1);
+            hipLaunchKernelGGL(k_store_tile<1>, dim3(4096), dim3(64), 0, 0, out, 8, 8);
+            CK(hipMemsetAsync(out, 0, out_elems * 4, 0));
+            CK(hipDeviceSynchronize());
+        }
+        return 0;
+    }
+    report("hipMemsetAsync 256MiB", T.us([&] { CK(hipMemsetAsync(out, 0, out_elems * 4, 0)); }), MB);
+    for (int g : {2048, 4096, 8192, 16384})
+    {
+        char nm[96];
+        snprintf(nm, 96, "store_linear256 nt grid=%d", g);
+        report(nm, T.us([&] { hipLaunchKernelGGL(k_store_linear256<0>, dim3(g), dim3(256), 0, 0, out, out_elems / 4); }), MB);
+        snprintf(nm, 96, "store_linear256 plain grid=%d", g);
+        report(nm, T.us([&] { hipLaunchKernelGGL(k_store_linear256<1>, dim3(g), dim3(256), 0, 0, out, out_elems / 4); }), MB);
+    }
+    for (int g : {4096, 8192, 32768}) {
+        char nm[96];
+        snprintf(nm, 96, "store_linear(wave 8KiB pieces) nt grid=%d", g);
+        report(nm, T.us([&] { hipLaunchKernelGGL(k_store_linear<0>, dim3(g), dim3(64), 0, 0, out, (unsigned)(out_elems / 2048)); }), MB);
+        snprintf(nm, 96, "store_linear(wave 8KiB pieces) plain grid=%d", g);
+        report(nm, T.us([&] { hipLaunchKernelGGL(k_store_linear<1>, dim3(g), dim3(64), 0, 0, out, (unsigned)(out_elems / 2048)); }), MB);
+    }
+    for (int g : {4096, 8192, 32768}) {
+        char nm[96];
+        snprintf(nm, 96, "store_tile(product pattern) nt grid=%d", g);
+        report(nm, T.us([&] { hipLaunchKernelGGL(k_store_tile<0>, dim3(g), dim3(64), 0, 0, out, 8, 8); }), MB);
+        snprintf(nm, 96, "store_tile(product pattern) plain grid=%d", g);
+        report(nm, T.us([&] { hipLaunchKernelGGL(k_store_tile<1>, dim3(g), dim3(64), 0, 0, out, 8, 8); }), MB);
+    }
+
+    report("store_aux plain(0)", T.us([&] { hipLaunchKernelGGL(k_store_aux<0>, dim3(4096), dim3(64), 0, 0, out, 8, 8); }), MB);
+    report("store_aux sc0(1)", T.us([&] { hipLaunchKernelGGL(k_store_aux<1>, dim3(4096), dim3(64), 0, 0, out, 8, 8); }), MB);
+    report("store_aux nt(2)", T.us([&] { hipLaunchKernelGGL(k_store_aux<2>, dim3(4096), dim3(64), 0, 0, out, 8, 8); }), MB);
+    report("store_aux sc0+nt(3)", T.us([&] { hipLaunchKernelGGL(k_store_aux<3>, dim3(4096), dim3(64), 0, 0, out, 8, 8); }), MB);
+    report("store_aux sc1(16)", T.us([&] { hipLaunchKernelGGL(k_store_aux<16>, dim3(4096), dim3(64), 0, 0, out, 8, 8); }), MB);
+    report("store_aux sc0+sc1(17)", T.us([&] { hipLaunchKernelGGL(k_store_aux<17>, dim3(4096), dim3(64), 0, 0, out, 8, 8); }), MB);
+    report("store_aux sc1+nt(18)", T.us([&] { hipLaunchKernelGGL(k_store_aux<18>, dim3(4096), dim3(64), 0, 0, out, 8, 8); }), MB);
+    report("store_aux sc0+sc1+nt(19)", T.us([&] { hipLaunchKernelGGL(k_store_aux<19>, dim3(4096), dim3(64), 0, 0, out, 8, 8); }), MB);
+    {
+        auto ta = [&](const char* name, auto kern) {
+            const int iters = 64, grid = 4096;
+            const double us = T.us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, 0, feat, iters, sink); }, 20, 3);
+            const double instr_per_cu = (double)grid * iters * 8 / 256;
+            printf("%-44s %9.2f us  %6.1f clk/instr/CU @2.1GHz\n", name, us, us * 2100.0 / instr_per_cu);
+        };
+        ta("ta_rate all lanes in range", k_ta_rate<0>);
+        ta("ta_rate half the groups OOB", k_ta_rate<1>);
+        ta("ta_rate 7/8 groups OOB", k_ta_rate<2>);
+        ta("ta_rate all OOB", k_ta_rate<3>);
+        ta("ta_rate half the groups exec-masked", k_ta_rate<4>);
+    }
+    // product stages
+    auto stage = [&](int s) {
+        int rc = rroi_align_forward_stages_hip(feat, 0, 0.25f, 1, R, H, W, C, PH, PW, rois_d, out, ws, wsb, 2, s, 0);
+        if (rc != 1) { fprintf(stderr, "stage rc=%d\n", rc); exit(1); }
+    };
+    stage(3);
+    CK(hipDeviceSynchronize());
+    report("product prologue", T.us([&] { stage(1); }), 52.4);
+    for (int aux : {2, 16}) {
+        rroi_align_debug_set_store_aux(aux);
+        for (int wpc : {6, 8, 9, 10, 11, 12, 13, 14}) {
+            rroi_align_debug_set_waves_per_cu(wpc);
+            char nm[96];
+            snprintf(nm, 96, "product gather one-wave aux=%d waves/CU=%d", aux, wpc);
+            report(nm, T.us([&] { stage(2); }, 100), MB);
+        }
+    }
+    rroi_align_debug_set_store_aux(16);
+    rroi_align_debug_set_waves_per_cu(12);
+    report("product all", T.us([&] { stage(3); }, 100), MB);
+
+    // gather-only, and the product gather, against the row pad of the chunk-major copy
+    const FastDiv dt = make_fastdiv(8), dp = make_fastdiv(PW);
+    rroi_align_debug_set_waves_per_cu(12);
+    for (int pad : {0, 1}) {
+        rroi_align_debug_set_row_pad(pad);
+        const Workspace w = carve(ws, 1, C, H, W, R, 0);
+        stage(1);
+        CK(hipDeviceSynchronize());
+        const int pitch = W + pad;
+        char nm[96];
+        for (int all : {0, 1}) {
+            snprintf(nm, 96, "gather_only pad=%d all_taps=%d", pad, all);
+            report(nm, T.us([&] {
+                hipLaunchKernelGGL(k_gather_only, dim3(4096), dim3(64), 0, 0, w.cm, w.aff, sink, 8, 8,
+                                   (unsigned)(H * pitch + 1) * 32, dt, dp, all, pitch);
+            }), MB);
+        }
+        snprintf(nm, 96, "product gather pad=%d", pad);
+        report(nm, T.us([&] { stage(2); }, 100), MB);
+    }
+    rroi_align_debug_set_row_pad(-1);
+    stage(1);
+    // raw gather bandwidth out of L2 / L1 (per-XCD slice sized regions)
+    {
+        const char* src = reinterpret_cast<const char*>(feat);
+        auto run = [&](const char* name, auto kern, unsigned region, int depth, int grid) {
+            const int iters = 256 / depth;
+            const double bytes = (double)grid * 64 * 16 * iters * depth;
+            const double us = T.us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, 0, src, region, iters, sink, 0); }, 20, 3);
+            printf("%-52s %9.2f us  %8.1f GB/s  %6.1f B/clk/CU@2.1GHz\n", name, us, bytes / us / 1e3, bytes / us / 1e3 / 256 / 2.1);
+            fflush(stdout);
+        };
+        auto run2 = [&](const char* name, auto kern, unsigned region, int depth, int grid, int mode) {
+            const int iters = 256 / depth;
+            const double bytes = (double)grid * 64 * 16 * iters * depth;
+            const double us = T.us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, 0, src, region, iters, sink, mode); }, 20, 3);
+            printf("%-52s %9.2f us  %8.1f GB/s  %6.1f B/clk/CU@2.1GHz\n", name, us, bytes / us / 1e3, bytes / us / 1e3 / 256 / 2.1);
+            fflush(stdout);
+        };
+        run2("l2 8x128B region=3MB shared by all   depth4", k_l2_gather<8, 4>, 3u << 20, 4, 4096, 0);
+        run2("l2 8x128B region=1MB shared by all   depth4", k_l2_gather<8, 4>, 1u << 20, 4, 4096, 0);
+        run2("l2 8x128B 3MB slice = block%8        depth4", k_l2_gather<8, 4>, 3u << 20, 4, 4096, 1);
+        run2("l2 8x128B 3MB slice = (block/8)%8    depth4", k_l2_gather<8, 4>, 3u << 20, 4, 4096, 2);
+        run2("l2 1KiB   3MB slice = block%8        depth4", k_l2_gather<64, 4>, 3u << 20, 4, 4096, 1);
+        run2("l2 8x128B 3MB slice = block%8        depth8", k_l2_gather<8, 8>, 3u << 20, 8, 4096, 1);
+        run2("l2 8x128B 3MB slice = block%8 grid8192 d4", k_l2_gather<8, 4>, 3u << 20, 4, 8192, 1);
+        const unsigned L2R = 24u << 20, L1R = 16u << 10;
+        for (int grid : {4096, 8192}) {
+            char nm[96];
+            snprintf(nm, 96, "l2 contiguous 1KiB depth1 grid=%d", grid); run(nm, k_l2_gather<64, 1>, L2R, 1, grid);
+            snprintf(nm, 96, "l2 contiguous 1KiB depth4 grid=%d", grid); run(nm, k_l2_gather<64, 4>, L2R, 4, grid);
+            snprintf(nm, 96, "l2 contiguous 1KiB depth8 grid=%d", grid); run(nm, k_l2_gather<64, 8>, L2R, 8, grid);
+            snprintf(nm, 96, "l2 8x128B lines   depth1 grid=%d", grid); run(nm, k_l2_gather<8, 1>, L2R, 1, grid);
+            snprintf(nm, 96, "l2 8x128B lines   depth4 grid=%d", grid); run(nm, k_l2_gather<8, 4>, L2R, 4, grid);
+            snprintf(nm, 96, "l2 8x128B lines   depth8 grid=%d", grid); run(nm, k_l2_gather<8, 8>, L2R, 8, grid);
+            snprintf(nm, 96, "l2 16x64B         depth4 grid=%d", grid); run(nm, k_l2_gather<4, 4>, L2R, 4, grid);
+            snprintf(nm, 96, "l2 64x16B         depth4 grid=%d", grid); run(nm, k_l2_gather<1, 4>, L2R, 4, grid);
+            snprintf(nm, 96, "L1 8x128B lines   depth4 grid=%d", grid); run(nm, k_l2_gather<8, 4>, L1R, 4, grid);
+            snprintf(nm, 96, "L1 contiguous     depth4 grid=%d", grid); run(nm, k_l2_gather<64, 4>, L1R, 4, grid);
+        }
+    }
+    return 0;
+}
