@@ -56,6 +56,18 @@ __device__ __forceinline__ unsigned fdiv(unsigned x, const FastDiv& f)
     return (t + ((x - t) >> f.sh1)) >> f.sh2;
 }
 
+// Ordering point for LDS traffic between the lanes of ONE wave (the tiled kernels run one
+// wave per workgroup).  LDS instructions of a wave execute in issue order, so a later
+// ds_read sees an earlier ds_write of another lane without any wait; all that is needed is
+// to stop the compiler from reordering them.  (__syncthreads() would also emit
+// s_waitcnt vmcnt(0), i.e. drain the tile's global stores.)
+__device__ __forceinline__ void lds_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float as_f(unsigned u) { return __uint_as_float(u); }
 __device__ __forceinline__ unsigned as_u(float f) { return __float_as_uint(f); }
 
@@ -217,93 +229,6 @@ struct SliceLayout {
     unsigned img_stride;    // floats  (fits: shape_ok bounds it)
 };
 
-// ------------------------------------------------------------------------------------
-// K0: forward prologue, one launch:
-//   blocks [0, relayout_blocks)      NCHW -> chunk-major: a [32 ch] x [128 px] tile goes
-//                                    through LDS; reads are 512 B runs of a channel row,
-//                                    writes are one contiguous 16 KiB run of the slice;
-//   then zero_blocks                 the zero pixel that ends every slice;
-//   then the rest                    per-ROI affine table (R x 32 B).
-// ------------------------------------------------------------------------------------
-constexpr int kRelayoutPx = 128;
-
-__global__ __launch_bounds__(256) void rroi_prologue_kernel(
-    const float* __restrict__ nchw, float* __restrict__ cm, int C, int HW, int width, int pitch,
-    FastDiv div_w, int nchunks, int ptiles, int relayout_blocks, int zero_blocks, int batch_size,
-    const float* __restrict__ rois, int num_rois, int pooled_height, float spatial_scale,
-    Affine* __restrict__ aff)
-{
-    __shared__ float T[kChunk * (kRelayoutPx + 1)];
-    const int tid = threadIdx.x;
-    const size_t zp_index = (size_t)(HW / width) * pitch;  // pixel index of the zero pixel
-    const size_t slice_stride = (zp_index + 1) * kChunk;
-    if ((int)blockIdx.x >= relayout_blocks + zero_blocks) {
-        const int n = ((int)blockIdx.x - relayout_blocks - zero_blocks) * 256 + tid;
-        if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
-        return;
-    }
-    if ((int)blockIdx.x >= relayout_blocks) {
-        const int i = ((int)blockIdx.x - relayout_blocks) * 256 + tid;  // (slice, channel-in-chunk)
-        if (i < batch_size * nchunks * kChunk)
-            cm[(size_t)(i / kChunk) * slice_stride + zp_index * kChunk + (i % kChunk)] = 0.0f;
-        return;
-    }
-    int bid = blockIdx.x;
-    const int pt = bid % ptiles;
-    bid /= ptiles;
-    const int k = bid % nchunks;
-    const int b = bid / nchunks;
-    const int lane = tid & 63, w = tid >> 6;
-    const int p0 = pt * kRelayoutPx, c0 = k * kChunk;
-    const float* src = nchw + ((size_t)b * C + c0) * HW + p0;
-    // wave w reads channels 8w..8w+7, two 64-pixel halves each
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = w * 8 + i;
-#pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-            const int p = hlf * 64 + lane;
-            float v = 0.0f;
-            if (c0 + c < C && p0 + p < HW) v = src[(size_t)c * HW + p];
-            T[c * (kRelayoutPx + 1) + p] = v;
-        }
-    }
-    __syncthreads();
-    // wave w writes pixels 32w..32w+31: per instruction 8 pixels x 128 B = 1 KiB contiguous
-    float* dst = cm + ((size_t)b * nchunks + k) * slice_stride;
-    const int cq = lane & 7, pl = lane >> 3;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = w * 32 + j * 8 + pl;
-        const float* tr = T + (cq * 4) * (kRelayoutPx + 1) + p;
-        v4f v = {tr[0], tr[kRelayoutPx + 1], tr[2 * (kRelayoutPx + 1)], tr[3 * (kRelayoutPx + 1)]};
-        const unsigned gp = (unsigned)(p0 + p);
-        const unsigned y = fdiv(gp, div_w);
-        const size_t pix = (size_t)y * pitch + (gp - y * (unsigned)width);
-        if (p0 + p < HW) *reinterpret_cast<v4f*>(dst + pix * kChunk + cq * 4) = v;
-    }
-}
-
-__global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois, int pooled_height,
-                                   float spatial_scale, Affine* __restrict__ aff)
-{
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
-}
-
-// ------------------------------------------------------------------------------------
-// K1: the hot kernel.  One wave per block; block -> channel chunk k = blockIdx %
-// nchunks (XCD affinity) and a grid-stride loop over (roi, 64-bin tile) items.
-//   phase A  lane = bin: geometry -> 32-byte tap record in LDS (4 byte offsets,
-//            flags, rx, ry).  With ZP an invalid tap (or any tap of a masked bin)
-//            points at the slice's zero pixel, so validity costs nothing later.
-//   phase B  lane = (bin b of 8, channel quad q of 8): first tap always, the
-//            other three only where the bin really has a second column / row,
-//            under the exec mask; taps that alias (dx == 0 / dy == 0) are
-//            resolved by register selects, which keeps the reference's four-term
-//            blend exact for non-finite features too; depth-2 software pipeline.
-//   phase C  the [32 ch][64 bin] tile leaves LDS as 16-byte stores, 256 B per row.
-// ------------------------------------------------------------------------------------
 // Buffer addressing: every tap load and every output store goes through a raw buffer
 // descriptor (base, num_records) whose range check does the predication in hardware -- a lane
 // whose byte offset is >= num_records reads zeros / stores nothing and costs no memory access.
@@ -337,14 +262,159 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned by
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, AUX);
 }
 
+// ------------------------------------------------------------------------------------
+// K0: forward prologue, one launch:
+//   blocks [0, relayout_blocks)      NCHW -> chunk-major: a [32 ch] x [128 px] tile goes
+//                                    through LDS; reads are 512 B runs of a channel row,
+//                                    writes are one contiguous 16 KiB run of the slice;
+//   then zero_blocks                 the zero pixel that ends every slice;
+//   then the rest                    per-ROI affine table (R x 32 B).
+// ------------------------------------------------------------------------------------
+constexpr int kRelayoutPx = 128;
+
+template <int AUX>
+__global__ __launch_bounds__(256) void rroi_prologue_kernel(
+    const float* __restrict__ nchw, float* __restrict__ cm, int C, int HW, int width, int pitch,
+    FastDiv div_w, int nchunks, int ptiles, int relayout_blocks, int relayout_tiles, int zero_blocks,
+    int batch_size, const float* __restrict__ rois, int num_rois, int pooled_height,
+    float spatial_scale, Affine* __restrict__ aff)
+{
+    // [32 ch][128 px] tile, 132-float pitch (16-byte aligned rows for the b128 writes); the
+    // pixel index of rows 8m..8m+7 is XORed with 4m so that the transposed ds_read_b32 of
+    // phase 2 (8 channel quads x 4 pixels per 32-lane group) hits 32 different banks.
+    constexpr int kTP = kRelayoutPx + 4;
+    __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
+    const int tid = threadIdx.x;
+    const size_t zp_index = (size_t)(HW / width) * pitch;  // pixel index of the zero pixel
+    const size_t slice_stride = (zp_index + 1) * kChunk;
+    if ((int)blockIdx.x >= relayout_blocks + zero_blocks) {
+        const int n = ((int)blockIdx.x - relayout_blocks - zero_blocks) * 256 + tid;
+        if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+        return;
+    }
+    if ((int)blockIdx.x >= relayout_blocks) {
+        const int i = ((int)blockIdx.x - relayout_blocks) * 256 + tid;  // (slice, channel-in-chunk)
+        if (i < batch_size * nchunks * kChunk)
+            cm[(size_t)(i / kChunk) * slice_stride + zp_index * kChunk + (i % kChunk)] = 0.0f;
+        return;
+    }
+    const int lane = tid & 63, w = tid >> 6;
+    // phase 1 mapping: lane -> 4 consecutive pixels (x4) of channel row (csub); a wave
+    // instruction reads two 512-byte runs.  phase 2 mapping: lane -> (channel quad, pixel).
+    const int x4 = lane & 31, csub = lane >> 5;
+    const int cq = lane & 7, pl = lane >> 3;
+    const bool vec_ok = (HW & 3) == 0;  // rows of 16-byte aligned float4 (p0 is a multiple of 128)
+
+    v4f r[4];
+    auto load_tile = [&](int tile) {
+        // chunk index fastest: with the grid a multiple of nchunks a block always relays out
+        // the same chunk, i.e. (8 chunks, blocks dealt round-robin to the 8 XCDs) slice k is
+        // written through the L2 of the XCD whose gather blocks will read it
+        const int k = tile % nchunks;
+        const int pt = (tile / nchunks) % ptiles;
+        const int b = tile / (ptiles * nchunks);
+        const int p0 = pt * kRelayoutPx, c0 = k * kChunk;
+        const float* src = nchw + ((size_t)b * C + c0) * HW + p0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = w * 8 + i * 2 + csub;
+            const int p = 4 * x4;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (c0 + c < C) {
+                const float* sp = src + (size_t)c * HW + p;
+                if (vec_ok && p0 + p + 3 < HW) {
+                    v = *reinterpret_cast<const v4f*>(sp);
+                } else {
+                    if (p0 + p + 0 < HW) v.x = sp[0];
+                    if (p0 + p + 1 < HW) v.y = sp[1];
+                    if (p0 + p + 2 < HW) v.z = sp[2];
+                    if (p0 + p + 3 < HW) v.w = sp[3];
+                }
+            }
+            r[i] = v;
+        }
+    };
+    // grid-stride over tiles, software-pipelined: the loads of the next tile are in flight
+    // while the current tile goes through LDS and out to the chunk-major copy
+    int tile = blockIdx.x;
+    if (tile < relayout_tiles) load_tile(tile);
+    while (tile < relayout_tiles) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = w * 8 + i * 2 + csub;
+            *reinterpret_cast<v4f*>(T + c * kTP + ((4 * x4) ^ ((c >> 3) * 4))) = r[i];
+        }
+        __syncthreads();
+        const int cur = tile;
+        tile += relayout_blocks;
+        if (tile < relayout_tiles) load_tile(tile);
+        {
+            const int k = cur % nchunks;
+            const int pt = (cur / nchunks) % ptiles;
+            const int b = cur / (ptiles * nchunks);
+            const int p0 = pt * kRelayoutPx;
+            float* dst = cm + ((size_t)b * nchunks + k) * slice_stride;
+            // wave w writes pixels 32w..32w+31: per instruction 8 pixels x 128 B = 1 KiB contiguous
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = w * 32 + j * 8 + pl;
+                const float* tr = T + (cq * 4) * kTP + (p ^ ((cq >> 1) * 4));
+                v4f v = {tr[0], tr[kTP], tr[2 * kTP], tr[3 * kTP]};
+                const unsigned gp = (unsigned)(p0 + p);
+                const unsigned y = fdiv(gp, div_w);
+                const size_t pix = (size_t)y * pitch + (gp - y * (unsigned)width);
+                if (p0 + p < HW) {
+                    if (AUX == 0) {
+                        *reinterpret_cast<v4f*>(dst + pix * kChunk + cq * 4) = v;
+                    } else {
+                        const __amdgpu_buffer_rsrc_t ws = make_rsrc(dst, (unsigned)(slice_stride * 4));
+                        buf_store<AUX>(ws, (unsigned)((pix * kChunk + cq * 4) * 4), v);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois, int pooled_height,
+                                   float spatial_scale, Affine* __restrict__ aff)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+}
+
+// ------------------------------------------------------------------------------------
+// K1: the hot kernel.  One wave per block; block -> channel chunk k = blockIdx %
+// nchunks (XCD affinity) and a grid-stride loop over (roi, 64-bin tile) items.
+//   phase A  lane = bin: geometry -> 32-byte tap record in LDS (4 byte offsets,
+//            flags, rx, ry).  With ZP an invalid tap (or any tap of a masked bin)
+//            points at the slice's zero pixel, so validity costs nothing later.
+//   phase B  lane = (bin b of 8, channel quad q of 8): first tap always, the
+//            other three only where the bin really has a second column / row,
+//            under the exec mask; taps that alias (dx == 0 / dy == 0) are
+//            resolved by register selects, which keeps the reference's four-term
+//            blend exact for non-finite features too; depth-2 software pipeline.
+//   phase C  the [32 ch][64 bin] tile leaves LDS as 16-byte stores, 256 B per row.
+// ------------------------------------------------------------------------------------
 template <bool VEC_STORE, int AUX>
 __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
-    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw)
+    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg)
 {
+    // A tile's bins are processed in CLASS-SORTED groups of 8, because the texture addresser
+    // charges 16 cycles for every dwordx4 wave instruction whatever the number of lanes that
+    // really fetch (measured: 16.1 / 15.6 / 15.2 clk with 0 / 50 / 87 % of the lanes out of
+    // range).  Issuing all 4 taps for all 64 bins costs 32 load instructions per tile although
+    // only ~1.3 taps per bin are distinct pixels.  Sorted:
+    //   LO  bins with at most two distinct taps (lt, and rt OR lb): 2 loads per group;
+    //   HI  bins with four distinct taps (dx and dy):                4 loads per group;
+    //   masked bins (pw > roi_pooled_width) are in no group -- phase C writes their zeros.
+    // Typical tile: 5 LO + 2 HI groups = 18 load instructions instead of 32.
+    constexpr int kMaxGroups = kIters + 2;  // two classes, each padded to a multiple of 8
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride];
-    __shared__ __attribute__((aligned(16))) uint4 G[kTileBins * 2];
+    __shared__ __attribute__((aligned(16))) uint4 G[kMaxGroups * kBinsPerIter * 2];
 
     const unsigned lane = threadIdx.x;
     const unsigned k = blockIdx.x % (unsigned)nchunks;
@@ -357,22 +427,28 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     // lane = q + 8*b: the 8 lanes that fetch the 8 channel quads of ONE pixel (one 128-byte
     // line) are consecutive, so the texture addresser merges them into two 64-byte
     // accesses.  (With the quads strided over the wave every lane costs its own access:
-    // measured 43 vs 16 TCP accesses per load instruction, TA busy 82 %.)
+    // measured 43 vs 16 TCP accesses per load instruction.)
     const unsigned q = lane & (kQuads - 1), b = lane >> 3;
     // a channel quad wholly beyond C never loads (its rows are not stored either)
-    const unsigned q_bytes = (k * kChunk + q * 4 < (unsigned)C) ? q * 16u : kOOB;
+    const unsigned q_bytes = ((dbg & 2) || k * kChunk + q * 4 >= (unsigned)C) ? kOOB : q * 16u;
     // LDS tile: row r = channel, 68-dword pitch; the column of rows 8m..8m+7 is XORed with
-    // 4*m so that the 32 lanes of a store group (8 quads x 4 bins) hit 32 different banks
+    // 4*m so that the 32 lanes of a store group (8 quads x 4 bins) spread over the banks
     // while rows stay 16-byte aligned for the ds_read_b128 of phase C.
     const unsigned wswz = (q >> 1) * 4u;  // rows 4q..4q+3 -> m = q >> 1
     const unsigned col = (lane & 15) * 4, row0 = lane >> 4;
     const unsigned chans_here = min((unsigned)kChunk, (unsigned)C - k * kChunk);  // rows of this chunk < C
     const v4f z4 = {0.f, 0.f, 0.f, 0.f};
 
-    // phase A of one item: lane = bin, geometry -> 32-byte tap record in LDS:
-    //   {off_lt, off_rt, off_lb, off_rb} byte offsets into the slice (kOOB = reads as 0.0),
-    //   {dx|dy flags, rx, ry, -}.
-    auto geometry = [&](const Affine& A, unsigned t) {
+    unsigned g_lo = 0, g_hi = 0;          // groups of the current item (wave-uniform)
+    unsigned long long act_mask = 0;      // bins of the current item that are in a group
+
+    // phase A of one item: lane = bin, geometry -> sorted 32-byte tap records in LDS:
+    //   LO: {off_lt, off_2nd, w_lt, w_2nd}      HI: {off_lt, off_rt, off_lb, off_rb}
+    //   both: {dx|dy flags | bin position << 8, rx, ry, -}
+    // Offsets are byte offsets into the slice; kOOB reads as 0.0, which is what
+    // kernel.cu:116-126 substitutes for a tap outside the map.
+    auto geometry = [&](const Affine& A, unsigned t, unsigned& n_lo_groups, unsigned& n_hi_groups,
+                        unsigned long long& amask) {
         const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
         const unsigned bin = t * kTileBins + lane;
         const unsigned ph = fdiv(bin, div_pw);
@@ -387,21 +463,37 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         const bool y0ok = y0 > 0 && y0 < height, y1ok = y1 > 0 && y1 < height;
         const bool dx = active && x1 != x0, dy = active && y1 != y0;
         // kernel.cu:116-126 validity; a tap that aliases lt (dx == 0 / dy == 0) is not loaded
-        const bool l00 = active && y0ok && x0ok;
-        const bool l01 = dx && y0ok && x1ok;
-        const bool l10 = dy && y1ok && x0ok;
-        const bool l11 = dx && dy && y1ok && x1ok;
         const unsigned o00 = (unsigned)y0 * row_bytes + (unsigned)x0 * px_bytes;
-        uint4 ra;
-        ra.x = l00 ? o00 : kOOB;
-        ra.y = l01 ? o00 + px_bytes : kOOB;
-        ra.z = l10 ? o00 + row_bytes : kOOB;
-        ra.w = l11 ? o00 + row_bytes + px_bytes : kOOB;
-        // a masked bin blends four zeros; give it clean weights (its centre may be NaN)
-        const float rx = active ? bcx - fx : 0.0f;
-        const float ry = active ? bcy - fy : 0.0f;
-        G[2 * lane + 0] = ra;
-        G[2 * lane + 1] = make_uint4((dx ? kDx : 0u) | (dy ? kDy : 0u), as_u(rx), as_u(ry), 0u);
+        const unsigned o_lt = (active && y0ok && x0ok) ? o00 : kOOB;
+        const unsigned o_rt = (dx && y0ok && x1ok) ? o00 + px_bytes : kOOB;
+        const unsigned o_lb = (dy && y1ok && x0ok) ? o00 + row_bytes : kOOB;
+        const unsigned o_rb = (dx && dy && y1ok && x1ok) ? o00 + row_bytes + px_bytes : kOOB;
+        const bool hi = dx && dy, lo = active && !hi;
+        const unsigned long long m_lo = __ballot(lo), m_hi = __ballot(hi);
+        const unsigned n_lo = __popcll(m_lo), n_hi = __popcll(m_hi);
+        n_lo_groups = (n_lo + kBinsPerIter - 1) / kBinsPerIter;
+        n_hi_groups = (n_hi + kBinsPerIter - 1) / kBinsPerIter;
+        amask = m_lo | m_hi;
+        const unsigned hi_base = n_lo_groups * kBinsPerIter;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned idx = lo ? __popcll(m_lo & below) : hi_base + __popcll(m_hi & below);
+        const float rx = bcx - fx, ry = bcy - fy;
+        float wlt, wrt, wrb, wlb;
+        tap_weights(rx, ry, wlt, wrt, wrb, wlb);
+        if (active) {
+            if (hi)
+                G[2 * idx + 0] = make_uint4(o_lt, o_rt, o_lb, o_rb);
+            else  // the one other distinct tap and its weight: rt (dx) or lb (dy); none -> 0 * 0
+                G[2 * idx + 0] = make_uint4(o_lt, dx ? o_rt : o_lb, as_u(wlt), as_u(dx ? wrt : wlb));
+            G[2 * idx + 1] = make_uint4((dx ? kDx : 0u) | (dy ? kDy : 0u) | (lane << 8), as_u(rx), as_u(ry), 0u);
+        }
+        // pad both classes to whole groups with records that load nothing and store nowhere
+        const unsigned pad_lo = hi_base - n_lo, pad_hi = n_hi_groups * kBinsPerIter - n_hi;
+        if (lane < pad_lo + pad_hi) {
+            const unsigned pidx = lane < pad_lo ? n_lo + lane : hi_base + n_hi + (lane - pad_lo);
+            G[2 * pidx + 0] = lane < pad_lo ? make_uint4(kOOB, kOOB, 0u, 0u) : make_uint4(kOOB, kOOB, kOOB, kOOB);
+            G[2 * pidx + 1] = make_uint4(64u << 8, 0u, 0u, 0u);
+        }
     };
     auto slice_rsrc = [&](const Affine& A) {
         const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
@@ -411,32 +503,76 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
 
     uint4 ra[2], rb[2];
     v4f lt[2], rt[2], lb[2], rbv[2];
-    auto fetch = [&](int it, int s) {
-        ra[s] = G[2 * (it * kBinsPerIter + b) + 0];
-        rb[s] = G[2 * (it * kBinsPerIter + b) + 1];
+    auto fetch = [&](unsigned grp, int s) {
+        ra[s] = G[2 * (grp * kBinsPerIter + b) + 0];
+        rb[s] = G[2 * (grp * kBinsPerIter + b) + 1];
     };
-    auto issue = [&](__amdgpu_buffer_rsrc_t rs, int s) {
+    auto issue_lo = [&](__amdgpu_buffer_rsrc_t rs, int s) {
         // kOOB + q_bytes (or anything + kOOB) stays out of range: no wrap below 2^32
+        lt[s] = buf_load(rs, ra[s].x + q_bytes);
+        rt[s] = buf_load(rs, ra[s].y + q_bytes);  // the bin's one other distinct tap, if any
+    };
+    auto issue_hi = [&](__amdgpu_buffer_rsrc_t rs, int s) {
         lt[s] = buf_load(rs, ra[s].x + q_bytes);
         rt[s] = buf_load(rs, ra[s].y + q_bytes);
         lb[s] = buf_load(rs, ra[s].z + q_bytes);
         rbv[s] = buf_load(rs, ra[s].w + q_bytes);
     };
+    auto put = [&](int s, v4f v) {
+        const unsigned pos = rb[s].x >> 8;
+        if (pos < (unsigned)kTileBins) {  // padding records store nowhere
+            float* tw = T + (q * 4) * kTStride + (pos ^ wswz);
+            tw[0 * kTStride] = v.x;
+            tw[1 * kTStride] = v.y;
+            tw[2 * kTStride] = v.z;
+            tw[3 * kTStride] = v.w;
+        }
+    };
+    auto blend4 = [&](int s, v4f t_lt, v4f t_rt, v4f t_rb, v4f t_lb) {
+        float wlt, wrt, wrb, wlb;
+        tap_weights(as_f(rb[s].y), as_f(rb[s].z), wlt, wrt, wrb, wlb);
+        v4f v = z4;  // kernel.cu:136-141, four channels at a time
+        v += t_lt * wlt;
+        v += t_rt * wrt;
+        v += t_rb * wrb;
+        v += t_lb * wlb;
+        return v;
+    };
+    auto blend_lo = [&](int s) {
+        // At most two distinct pixels.  The reference still adds all four terms
+        // (kernel.cu:138-141); the two that re-read a pixel carry weight exactly 0 (rx or ry
+        // is 0), so for finite taps they add +-0 and  (0 + lt*w_lt) + t2*w_2nd  is the same
+        // value bit for bit.  Both distinct taps have non-zero weights, so a non-finite tap
+        // makes this result non-finite -- only then (0 * inf = NaN in the reference) the
+        // four-term form is evaluated.
+        const v4f t_lt = lt[s], t_2 = rt[s];
+        v4f v = z4;
+        v += t_lt * as_f(ra[s].z);
+        v += t_2 * as_f(ra[s].w);
+        const v4f d = v - v;  // 0 for finite lanes, NaN otherwise
+        if (__builtin_expect(__any((d.x + d.y) + (d.z + d.w) != 0.0f), 0)) {
+            const unsigned f = rb[s].x;
+            const bool dx = f & kDx, dy = f & kDy;
+            v = blend4(s, t_lt, dx ? t_2 : t_lt, (dx || dy) ? t_2 : t_lt, dy ? t_2 : t_lt);
+        }
+        put(s, v);
+    };
+    auto blend_hi = [&](int s) { put(s, blend4(s, lt[s], rt[s], rbv[s], lb[s])); };
+    // An empty asm that "rewrites" the current group's taps: placed right after the next
+    // group's loads are issued, it pins the first use of the current taps (and with it the
+    // s_waitcnt) BEHIND that issue.  Without it the compiler hoists the first multiplies of the
+    // blend above the "more groups?" branch and waits before anything new is in flight.
+    auto pin_lo = [&](int s) { asm volatile("" : "+v"(lt[s]), "+v"(rt[s])); };
+    auto pin_hi = [&](int s) { asm volatile("" : "+v"(lt[s]), "+v"(rt[s]), "+v"(lb[s]), "+v"(rbv[s])); };
 
-    // The item loop is software-pipelined ACROSS items: while item i is blended and
-    // streamed out, the affine of item i+1 is already loaded, its records are built as
-    // soon as item i has fetched its last record, and its first taps are in flight
-    // before item i's stores are issued.
     unsigned item = slot;
     if (item >= items) return;
     unsigned n = fdiv(item, div_tiles);
     unsigned t = item - n * (unsigned)ntiles;
     Affine A = aff[n];
-    geometry(A, t);
-    __syncthreads();
+    geometry(A, t, g_lo, g_hi, act_mask);
+    lds_wave_sync();
     __amdgpu_buffer_rsrc_t rs = slice_rsrc(A);
-    fetch(0, 0);
-    issue(rs, 0);
 
     for (;;) {
         const unsigned item_next = item + nslots;
@@ -445,52 +581,68 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         const unsigned t_next = item_next - n_next * (unsigned)ntiles;
         const Affine A_next = aff[n_next];  // in flight during phase B
 
-        // ---- phase B of the current item -------------------------------------------------
+        // ---- phase B: LO groups, then HI groups; the loads of group g+1 are issued before
+        // group g is blended.  The loops are unrolled with an early exit, and the two exit
+        // paths end in different (empty) asm statements so that the compiler cannot merge
+        // their tails: each blend then has ONE predecessor and its s_waitcnt knows exactly
+        // how many younger loads are in flight.
+        if (g_lo > 0) {
+            fetch(0, 0);
+            issue_lo(rs, 0);
 #pragma unroll
-        for (int it = 0; it < kIters; ++it) {
-            const int s = it & 1;
-            if (it + 1 < kIters) {
-                fetch(it + 1, s ^ 1);
-                issue(rs, s ^ 1);
+            for (int it = 0; it < kIters; ++it) {
+                const int s = it & 1;
+                if ((unsigned)(it + 1) < g_lo) {
+                    fetch(it + 1, s ^ 1);
+                    issue_lo(rs, s ^ 1);
+                    pin_lo(s);
+                    blend_lo(s);
+                    asm volatile("; lo: more groups follow");
+                } else {
+                    blend_lo(s);
+                    asm volatile("; lo: last group");
+                    break;
+                }
             }
-            const unsigned f = rb[s].x;
-            const bool dx = f & kDx, dy = f & kDy;
-            // kernel.cu:110-126 read the same pixel again when floor == ceil
-            const v4f t_lt = lt[s];
-            const v4f t_rt = dx ? rt[s] : t_lt;
-            const v4f t_lb = dy ? lb[s] : t_lt;
-            const v4f t_rb = dx ? (dy ? rbv[s] : t_rt) : t_lb;
-            float wlt, wrt, wrb, wlb;
-            tap_weights(as_f(rb[s].y), as_f(rb[s].z), wlt, wrt, wrb, wlb);
-            v4f v = z4;  // kernel.cu:136-141, four channels at a time
-            v += t_lt * wlt;
-            v += t_rt * wrt;
-            v += t_rb * wrb;
-            v += t_lb * wlb;
-            float* tw = T + (q * 4) * kTStride + ((it * kBinsPerIter + b) ^ wswz);
-            tw[0 * kTStride] = v.x;
-            tw[1 * kTStride] = v.y;
-            tw[2 * kTStride] = v.z;
-            tw[3 * kTStride] = v.w;
         }
+        if (g_hi > 0) {
+            fetch(g_lo, 0);
+            issue_hi(rs, 0);
+#pragma unroll
+            for (int it = 0; it < kIters; ++it) {
+                const int s = it & 1;
+                if ((unsigned)(it + 1) < g_hi) {
+                    fetch(g_lo + it + 1, s ^ 1);
+                    issue_hi(rs, s ^ 1);
+                    pin_hi(s);
+                    blend_hi(s);
+                    asm volatile("; hi: more groups follow");
+                } else {
+                    blend_hi(s);
+                    asm volatile("; hi: last group");
+                    break;
+                }
+            }
+        }
+        const unsigned long long cur_mask = act_mask;
         // every record of this item has been fetched: G is free for the next item
+        lds_wave_sync();
         __amdgpu_buffer_rsrc_t rs_next = rs;
         if (has_next) {
-            geometry(A_next, t_next);
+            geometry(A_next, t_next, g_lo, g_hi, act_mask);
             rs_next = slice_rsrc(A_next);
         }
-        __syncthreads();
-        if (has_next) {
-            fetch(0, 0);
-            issue(rs_next, 0);
-        }
+        lds_wave_sync();
 
         // ---- phase C of the current item: [rows < C] x [64 bins] -> 256-byte row segments ----
-        {
+        if (!(dbg & 1)) {  // (ablation knob: dbg & 1 skips the output stores)
             // descriptor over this (roi, chunk) block of the output: rows >= C fall out of range
             float* obase = out + ((size_t)n * C + k * kChunk) * NB;
             const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, chans_here * (unsigned)NB * 4u);
             const unsigned bin0 = t * kTileBins + col;
+            // bins that were in no group (masked by pw > roi_pooled_width) are zero
+            const unsigned nib = (unsigned)(cur_mask >> col) & 15u;
+            const bool a0 = nib & 1u, a1 = nib & 2u, a2 = nib & 4u, a3 = nib & 8u;
             v4f v[kChunk / 4];
 #pragma unroll
             for (int s = 0; s < kChunk / 4; ++s) {
@@ -501,17 +653,18 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
             for (int s = 0; s < kChunk / 4; ++s) {
                 const unsigned r = s * 4 + row0;
                 const unsigned off = (r * (unsigned)NB + bin0) * 4u;
+                const v4f o = {a0 ? v[s].x : 0.f, a1 ? v[s].y : 0.f, a2 ? v[s].z : 0.f, a3 ? v[s].w : 0.f};
                 if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
-                    buf_store<AUX>(ws, bin0 < (unsigned)NB ? off : kOOB, v[s]);
+                    buf_store<AUX>(ws, bin0 < (unsigned)NB ? off : kOOB, o);
                 } else {
-                    buf_store1<AUX>(ws, bin0 + 0 < (unsigned)NB ? off + 0 : kOOB, v[s].x);
-                    buf_store1<AUX>(ws, bin0 + 1 < (unsigned)NB ? off + 4 : kOOB, v[s].y);
-                    buf_store1<AUX>(ws, bin0 + 2 < (unsigned)NB ? off + 8 : kOOB, v[s].z);
-                    buf_store1<AUX>(ws, bin0 + 3 < (unsigned)NB ? off + 12 : kOOB, v[s].w);
+                    buf_store1<AUX>(ws, bin0 + 0 < (unsigned)NB ? off + 0 : kOOB, o.x);
+                    buf_store1<AUX>(ws, bin0 + 1 < (unsigned)NB ? off + 4 : kOOB, o.y);
+                    buf_store1<AUX>(ws, bin0 + 2 < (unsigned)NB ? off + 8 : kOOB, o.z);
+                    buf_store1<AUX>(ws, bin0 + 3 < (unsigned)NB ? off + 12 : kOOB, o.w);
                 }
             }
         }
-        __syncthreads();
+        lds_wave_sync();
         if (!has_next) break;
         item = item_next;
         n = n_next;
@@ -952,6 +1105,9 @@ bool pick_tiled(int batch_size, int channels, int height, int width, int num_roi
 }
 
 int g_store_aux = 16;  // exploration knob: cache policy of the output stores
+int g_fwd_dbg = 0;     // ablation: 1 = skip output stores, 2 = all taps out of range
+int g_prologue_blocks_per_cu = 3;
+int g_prologue_aux = 0;
 
 }  // namespace
 
@@ -1033,14 +1189,26 @@ int rroi_align_forward_stages_hip(const float* features, int feature_layout, flo
     // prologue: relayout + zero pixels + affine table in one launch
     if (stages & RROI_STAGE_PROLOGUE) {
         const int ptiles = ceil_div(HW, kRelayoutPx);
-        const int relayout_blocks = zero_copy ? 0 : ptiles * nchunks * batch_size;
+        const int relayout_tiles = zero_copy ? 0 : ptiles * nchunks * batch_size;
+        // ~3 resident blocks per CU, each streaming several tiles with the next tile prefetched
+        int relayout_blocks = relayout_tiles;
+        if (relayout_blocks > num_cus() * g_prologue_blocks_per_cu) {
+            relayout_blocks = num_cus() * g_prologue_blocks_per_cu;
+            long unit = nchunks;
+            while (unit % 8) unit += nchunks;  // lcm(nchunks, 8): keeps block -> chunk -> XCD stable
+            if (relayout_blocks >= unit) relayout_blocks = (int)(relayout_blocks / unit * unit);
+        }
         const int zero_blocks = zero_copy ? 0 : ceil_div((long)batch_size * nchunks * kChunk, 256);
         const int aff_blocks = ceil_div(num_rois, 256);
-        hipLaunchKernelGGL(rroi_prologue_kernel, dim3(relayout_blocks + zero_blocks + aff_blocks),
-                           dim3(256), 0, stream, features, ws.cm, channels, HW, width, pitch,
-                           make_fastdiv((unsigned)width), nchunks, ptiles, relayout_blocks,
-                           zero_blocks, batch_size, rois, num_rois, pooled_height, spatial_scale,
-                           ws.aff);
+#define RROI_LAUNCH_PRO(AUX)                                                                        \
+    hipLaunchKernelGGL(rroi_prologue_kernel<AUX>, dim3(relayout_blocks + zero_blocks + aff_blocks),   \
+                       dim3(256), 0, stream, features, ws.cm, channels, HW, width, pitch,             \
+                       make_fastdiv((unsigned)width), nchunks, ptiles, relayout_blocks,               \
+                       relayout_tiles, zero_blocks, batch_size, rois, num_rois, pooled_height,        \
+                       spatial_scale, ws.aff)
+        if (g_prologue_aux == 16) RROI_LAUNCH_PRO(16);
+        else RROI_LAUNCH_PRO(0);
+#undef RROI_LAUNCH_PRO
         const int st = launch_status();
         if (st != 1) return st;
     }
@@ -1066,7 +1234,7 @@ int rroi_align_forward_stages_hip(const float* features, int feature_layout, flo
 #define RROI_LAUNCH_FWD(VEC, AUX)                                                                    \
     hipLaunchKernelGGL((rroi_fwd_tiled_kernel<VEC, AUX>), dim3(grid), dim3(kWave), 0, stream, map,   \
                        ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,        \
-                       batch_size, nchunks, ntiles, lay, dt, dp)
+                       batch_size, nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
         if (NB % 4 != 0) RROI_LAUNCH_FWD(false, 16);
         else if (g_store_aux == 0) RROI_LAUNCH_FWD(true, 0);   // exploration only
         else if (g_store_aux == 2) RROI_LAUNCH_FWD(true, 2);   // exploration only
@@ -1081,6 +1249,24 @@ int rroi_align_debug_set_store_aux(int v)
 {
     const int old = g_store_aux;
     g_store_aux = v;
+    return old;
+}
+int rroi_align_debug_set_fwd_dbg(int v)
+{
+    const int old = g_fwd_dbg;
+    g_fwd_dbg = v;
+    return old;
+}
+int rroi_align_debug_set_prologue_blocks(int v)
+{
+    const int old = g_prologue_blocks_per_cu;
+    if (v >= 1 && v <= 64) g_prologue_blocks_per_cu = v;
+    return old;
+}
+int rroi_align_debug_set_prologue_aux(int v)
+{
+    const int old = g_prologue_aux;
+    g_prologue_aux = v;
     return old;
 }
 int rroi_align_debug_set_row_pad(int v)

@@ -73,63 +73,6 @@ __global__ __launch_bounds__(256) void k_store_linear256(float* __restrict__ out
     }
 }
 
-// ---- gather-only: product phase A+B, the tile is reduced instead of stored ------------------
-__global__ __launch_bounds__(64) void k_gather_only(const float* __restrict__ pm, const Affine* __restrict__ aff,
-                                                   float* __restrict__ sink, int nchunks, int ntiles,
-                                                   unsigned img_stride, FastDiv div_tiles, FastDiv div_pw,
-                                                   int all_taps, int pitch)
-{
-    __shared__ __attribute__((aligned(16))) uint4 G[64 * 2];
-    const unsigned lane = threadIdx.x;
-    const unsigned k = blockIdx.x % nchunks, slot = blockIdx.x / nchunks, nslots = gridDim.x / nchunks;
-    const unsigned items = R * ntiles;
-    const unsigned px_bytes = 128u, zp_bytes = H * pitch * px_bytes;
-    const unsigned q = lane & 7, b = lane >> 3;
-    const unsigned ch_bytes = q * 16u;
-    v4f acc = {0.f, 0.f, 0.f, 0.f};
-    for (unsigned item = slot; item < items; item += nslots) {
-        const unsigned n = fdiv(item, div_tiles);
-        const unsigned t = item - n * ntiles;
-        const Affine A = aff[n];
-        {
-            const unsigned bin = t * 64 + lane;
-            const unsigned ph = fdiv(bin, div_pw), pw = bin - ph * PW;
-            float bcx, bcy;
-            bool active = bin_centre(A, ph, pw, H, W, bcx, bcy);
-            const float fx = floorf(bcx), fy = floorf(bcy);
-            const int x0 = f2i_sat(fx), x1 = f2i_sat(ceilf(bcx)), y0 = f2i_sat(fy), y1 = f2i_sat(ceilf(bcy));
-            const bool x0ok = x0 > 0 && x0 < W, x1ok = x1 > 0 && x1 < W, y0ok = y0 > 0 && y0 < H, y1ok = y1 > 0 && y1 < H;
-            const bool dx = active && x1 != x0, dy = active && y1 != y0;
-            const unsigned o00 = ((unsigned)y0 * pitch + (unsigned)x0) * px_bytes, rowb = pitch * px_bytes;
-            uint4 ra;
-            ra.x = active && y0ok && x0ok ? o00 : zp_bytes;
-            ra.y = active && y0ok && x1ok ? o00 + px_bytes : zp_bytes;
-            ra.z = active && y1ok && x0ok ? o00 + rowb : zp_bytes;
-            ra.w = active && y1ok && x1ok ? o00 + rowb + px_bytes : zp_bytes;
-            unsigned f = (active && y0ok && x0ok ? kL0 : 0) | (dx && y0ok && x1ok ? kL1 : 0u) |
-                         (dy && y1ok && x0ok ? kL2 : 0u) | (dx && dy && y1ok && x1ok ? kL3 : 0u);
-            if (all_taps) f = kL0 | kL1 | kL2 | kL3;
-            G[2 * lane] = ra;
-            G[2 * lane + 1] = make_uint4(f, 0, 0, 0);
-        }
-        __syncthreads();
-        const char* base = reinterpret_cast<const char*>(pm + (size_t)k * img_stride);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const uint4 ra = G[2 * (it * 8 + b)];
-            const unsigned f = G[2 * (it * 8 + b) + 1].x;
-            v4f a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
-            if (f & kL0) a0 = *reinterpret_cast<const v4f*>(base + (size_t)(ra.x + ch_bytes));
-            if (f & kL1) a1 = *reinterpret_cast<const v4f*>(base + (size_t)(ra.y + ch_bytes));
-            if (f & kL2) a2 = *reinterpret_cast<const v4f*>(base + (size_t)(ra.z + ch_bytes));
-            if (f & kL3) a3 = *reinterpret_cast<const v4f*>(base + (size_t)(ra.w + ch_bytes));
-            acc += (a0 + a1) + (a2 + a3);
-        }
-        __syncthreads();
-    }
-    if (acc.x == 12345.678f) sink[blockIdx.x * 64 + lane] = acc.x + acc.y + acc.z + acc.w;
-}
-
 // ---- raw L2->CU gather bandwidth: every lane group of LPG lanes reads one contiguous run of
 // LPG*16 bytes at a pseudo-random offset inside `region_bytes`; DEPTH independent loads in
 // flight per wave.  LPG = 64: 1 KiB contiguous per instruction; 8: eight 128 B lines; 1: 64 x 16 B.
@@ -275,17 +218,10 @@ int main(int argc, char** argv)
             int rc = rroi_align_forward_stages_hip(feat, 0, 0.25f, 1, R, H, W, C, PH, PW, rois_d, out, ws, wsb, 2, s, 0);
             if (rc != 1) { fprintf(stderr, "stage rc=%d\n", rc); exit(1); }
         };
-        const Workspace w = carve(ws, 1, C, H, W, R, 0);
-        const FastDiv dt = make_fastdiv(8), dp = make_fastdiv(PW);
-        const int pitch = row_pitch(W);
         for (int rep = 0; rep < 3; ++rep) {
             stage(1);
             stage(2);
             if (argc > 2) continue;  // "pmc product": the product kernels only
-            hipLaunchKernelGGL(k_gather_only, dim3(4096), dim3(64), 0, 0, w.cm, w.aff, sink, 8, 8,
-                               (unsigned)(H * pitch + 1) * 32, dt, dp, 0, pitch);
-            hipLaunchKernelGGL(k_gather_only, dim3(4096), dim3(64), 0, 0, w.cm, w.aff, sink, 8, 8,
-                               (unsigned)(H * pitch + 1) * 32, dt, dp, 1, pitch);
             hipLaunchKernelGGL((k_l2_gather<8, 4>), dim3(4096), dim3(64), 0, 0, (const char*)feat, 3u << 20, 64, sink, 1);
             hipLaunchKernelGGL(k_store_tile<1>, dim3(4096), dim3(64), 0, 0, out, 8, 8);
             CK(hipMemsetAsync(out, 0, out_elems * 4, 0));
@@ -345,42 +281,38 @@ int main(int argc, char** argv)
     };
     stage(3);
     CK(hipDeviceSynchronize());
-    report("product prologue", T.us([&] { stage(1); }), 52.4);
-    for (int aux : {2, 16}) {
-        rroi_align_debug_set_store_aux(aux);
-        for (int wpc : {6, 8, 9, 10, 11, 12, 13, 14}) {
-            rroi_align_debug_set_waves_per_cu(wpc);
+    for (int paux : {0, 2, 16}) {
+        rroi_align_debug_set_prologue_aux(paux);
+        char nm[96];
+        snprintf(nm, 96, "product prologue aux=%d warm", paux);
+        report(nm, T.us([&] { stage(1); }), 52.4);
+        snprintf(nm, 96, "product prologue aux=%d after 256MiB fill", paux);
+        const double both = T.us([&] { CK(hipMemsetAsync(out, 0, out_elems * 4, 0)); stage(1); });
+        const double fill = T.us([&] { CK(hipMemsetAsync(out, 0, out_elems * 4, 0)); });
+        report(nm, both - fill, 52.4);
+        snprintf(nm, 96, "product all, prologue aux=%d", paux);
+        report(nm, T.us([&] { stage(3); }, 100), MB);
+        // steady-state pipeline: 20 back-to-back steps between two events
+        const double pipe = T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 10, 2) / 20;
+        snprintf(nm, 96, "pipeline step (20 back-to-back), prologue aux=%d", paux);
+        report(nm, pipe, MB);
+    }
+    rroi_align_debug_set_prologue_aux(0);
+    rroi_align_debug_set_prologue_blocks(3);
+    rroi_align_debug_set_store_aux(16);
+    for (int wpc : {10, 12, 14}) {
+        rroi_align_debug_set_waves_per_cu(wpc);
+        for (int dbg : {0, 1, 2, 3}) {
+            rroi_align_debug_set_fwd_dbg(dbg);
             char nm[96];
-            snprintf(nm, 96, "product gather one-wave aux=%d waves/CU=%d", aux, wpc);
+            snprintf(nm, 96, "gather %d waves/CU ablation=%d%s%s", wpc, dbg, dbg & 1 ? " no-stores" : "", dbg & 2 ? " no-taps" : "");
             report(nm, T.us([&] { stage(2); }, 100), MB);
         }
     }
-    rroi_align_debug_set_store_aux(16);
+    rroi_align_debug_set_fwd_dbg(0);
     rroi_align_debug_set_waves_per_cu(12);
     report("product all", T.us([&] { stage(3); }, 100), MB);
 
-    // gather-only, and the product gather, against the row pad of the chunk-major copy
-    const FastDiv dt = make_fastdiv(8), dp = make_fastdiv(PW);
-    rroi_align_debug_set_waves_per_cu(12);
-    for (int pad : {0, 1}) {
-        rroi_align_debug_set_row_pad(pad);
-        const Workspace w = carve(ws, 1, C, H, W, R, 0);
-        stage(1);
-        CK(hipDeviceSynchronize());
-        const int pitch = W + pad;
-        char nm[96];
-        for (int all : {0, 1}) {
-            snprintf(nm, 96, "gather_only pad=%d all_taps=%d", pad, all);
-            report(nm, T.us([&] {
-                hipLaunchKernelGGL(k_gather_only, dim3(4096), dim3(64), 0, 0, w.cm, w.aff, sink, 8, 8,
-                                   (unsigned)(H * pitch + 1) * 32, dt, dp, all, pitch);
-            }), MB);
-        }
-        snprintf(nm, 96, "product gather pad=%d", pad);
-        report(nm, T.us([&] { stage(2); }, 100), MB);
-    }
-    rroi_align_debug_set_row_pad(-1);
-    stage(1);
     // raw gather bandwidth out of L2 / L1 (per-XCD slice sized regions)
     {
         const char* src = reinterpret_cast<const char*>(feat);
