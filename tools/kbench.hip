@@ -156,6 +156,33 @@ __global__ __launch_bounds__(64) void k_ta_rate(const float* __restrict__ src, i
     if (acc.x == 12345.678f) sink[blockIdx.x * 64 + lane] = acc.x + acc.y + acc.z + acc.w;
 }
 
+// ---- fp32 atomic-add throughput into an L2-resident slice (3 MiB per XCD, block %% 8 affinity).
+// MODE 0: dense   -- 32 consecutive floats of 2 random pixels per instruction (2 full lines)
+// MODE 1: strided -- 8 random pixels per instruction, lane q of a pixel adds to float 4q+j
+// MODE 2: dense, all waves hammer 64 hot pixels (contention)
+template <int MODE>
+__global__ __launch_bounds__(64) void k_atomic(float* __restrict__ dst0, int iters)
+{
+    const unsigned lane = threadIdx.x;
+    float* dst = dst0 + (size_t)(blockIdx.x % 8) * (3u << 18);  // 3 MiB slices
+    const unsigned npx = (3u << 20) / 128;
+    unsigned state = (blockIdx.x * 64u + (MODE == 1 ? (lane >> 3) : (lane >> 5))) * 2654435761u + 12345u;
+    for (int i = 0; i < iters; ++i) {
+        state = state * 1664525u + 1013904223u;
+        unsigned p = (unsigned)(((unsigned long long)(state >> 8) * npx) >> 24);
+        if (MODE == 2) p &= 63u;
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dst + (size_t)p * 32 + (lane & 7) * 4 + j, 1.0f);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsafeAtomicAdd(dst + (size_t)((p + j * 977u) % npx) * 32 + (lane & 31), 1.0f);
+            }
+        }
+    }
+}
+
 struct Timer {
     hipEvent_t a, b;
     Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
@@ -273,6 +300,18 @@ int main(int argc, char** argv)
         ta("ta_rate 7/8 groups OOB", k_ta_rate<2>);
         ta("ta_rate all OOB", k_ta_rate<3>);
         ta("ta_rate half the groups exec-masked", k_ta_rate<4>);
+    }
+    {
+        auto at = [&](const char* name, auto kern) {
+            const int iters = 64, grid = 4096;
+            const double us = T.us([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, 0, feat, iters); }, 10, 2);
+            const double instr = (double)grid * iters * 4;
+            printf("%-44s %9.2f us  %7.2f G lane-atomics/s  %6.1f clk/instr/CU @2.1GHz\n", name, us,
+                   instr * 64 / us / 1e3, us * 2100.0 / (instr / 256));
+        };
+        at("atomic f32 dense (2 lines/instr)", k_atomic<0>);
+        at("atomic f32 strided (8 lines/instr)", k_atomic<1>);
+        at("atomic f32 dense, 64 hot pixels", k_atomic<2>);
     }
     // product stages
     auto stage = [&](int s) {
