@@ -728,10 +728,14 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// Backward, tiled: scatter into a chunk-major gradient (B, C/32, H*W, 32), zeroed,
-// with hardware fp32 atomics: 8 lanes x 4 channels cover one 128-byte line of a
-// pixel, all atomics of chunk k resolve in the L2 of the XCD that owns k; then
-// relayout to NCHW.  Same item decomposition as the forward.
+// Backward, tiled: scatter into a zeroed chunk-major gradient (B, C/32, H*Wp, 32) with
+// hardware fp32 atomics, then relayout to NCHW.  Same item decomposition as the forward.
+// Measured on MI355X (tools/kbench): an atomic wave instruction that covers 2 full 128-byte
+// lines sustains 325 G lane-atomics/s, one that touches 8 lines at a 16-byte stride only
+// 80 G/s.  So the (bin, tap) contributions of a tile are first COMPACTED into a list (only
+// the taps that pass the reference's bounds, kernel.cu:267-274), and the scatter loop takes
+// two list entries per instruction: lanes 0-31 add the 32 channels of one pixel, lanes 32-63
+// those of another.
 // ------------------------------------------------------------------------------------
 template <bool VEC_LOAD>
 __global__ __launch_bounds__(kWave) void rroi_bwd_tiled_kernel(
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(kWave) void rroi_bwd_tiled_kernel(
     int nchunks, int ntiles, FastDiv div_tiles, FastDiv div_pw)
 {
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride];
-    __shared__ __attribute__((aligned(16))) uint4 G[kTileBins];
+    __shared__ __attribute__((aligned(16))) uint4 P[kTileBins * 4];  // {float offset of the pixel, weight, bin, -}
 
     const unsigned lane = threadIdx.x;
     const unsigned k = blockIdx.x % (unsigned)nchunks;
@@ -748,16 +752,17 @@ __global__ __launch_bounds__(kWave) void rroi_bwd_tiled_kernel(
     const unsigned nslots = gridDim.x / (unsigned)nchunks;
     const unsigned items = (unsigned)num_rois * (unsigned)ntiles;
     const unsigned slice_px = (unsigned)height * (unsigned)pitch;
-    const unsigned q = lane & (kQuads - 1), b = lane >> 3;  // as in the forward: a pixel's quads are adjacent lanes
-    const unsigned wswz = (q >> 1) * 4u;
     const unsigned col = (lane & 15) * 4, row0 = lane >> 4;
-    const unsigned cvalid = (unsigned)C - min((unsigned)C, k * kChunk + q * 4);  // channels of this quad < C
+    const unsigned c = lane & 31, half = lane >> 5;   // scatter phase: channel within the chunk, list parity
+    const bool c_ok = k * kChunk + c < (unsigned)C;
+    const unsigned long long below = (1ull << lane) - 1ull;
 
     for (unsigned item = slot; item < items; item += nslots) {
         const unsigned n = fdiv(item, div_tiles);
         const unsigned t = item - n * (unsigned)ntiles;
         const Affine A = aff[n];
         const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
+        unsigned npairs;
         {
             const unsigned bin = t * kTileBins + lane;
             const unsigned ph = fdiv(bin, div_pw);
@@ -769,13 +774,25 @@ __global__ __launch_bounds__(kWave) void rroi_bwd_tiled_kernel(
             // scatter happens exactly where the forward's mask holds.
             bool active = bin_centre(A, (int)ph, (int)pw, height, width, bcx, bcy);
             active = active && bin < (unsigned)NB && batch_ok;
-            Taps tp = make_taps(bcx, bcy, active, height, width, kChunk);
-            // re-base the first tap on the padded row pitch of the chunk-major gradient
-            {
-                const int x0 = f2i_sat(floorf(bcx)), y0 = f2i_sat(floorf(bcy));
-                tp.o_lt = ((unsigned)y0 * (unsigned)pitch + (unsigned)x0) * kChunk;
-            }
-            G[lane] = make_uint4(tp.o_lt, tp.flags, as_u(tp.rx), as_u(tp.ry));
+            const Taps tp = make_taps(bcx, bcy, active, height, width, 1u);
+            float wlt, wrt, wrb, wlb;
+            tap_weights(tp.rx, tp.ry, wlt, wrt, wrb, wlb);
+            const unsigned f = tp.flags;
+            // pixel index on the padded row pitch of the chunk-major gradient, as a float offset
+            const int x0 = f2i_sat(floorf(bcx)), y0 = f2i_sat(floorf(bcy));
+            const unsigned o_lt = ((unsigned)y0 * (unsigned)pitch + (unsigned)x0) * kChunk;
+            const unsigned o_rt = o_lt + ((f & kDx) ? (unsigned)kChunk : 0u);
+            const unsigned o_lb = o_lt + ((f & kDy) ? (unsigned)pitch * kChunk : 0u);
+            const unsigned o_rb = o_lb + ((f & kDx) ? (unsigned)kChunk : 0u);
+            // compaction: list order = all lt entries, then rt, rb, lb (kernel.cu:267-274 order)
+            const unsigned long long m0 = __ballot(f & kB00), m1 = __ballot(f & kB01);
+            const unsigned long long m2 = __ballot(f & kB11), m3 = __ballot(f & kB10);
+            const unsigned n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2);
+            npairs = n0 + n1 + n2 + (unsigned)__popcll(m3);
+            if (f & kB00) P[__popcll(m0 & below)] = make_uint4(o_lt, as_u(wlt), lane, 0u);
+            if (f & kB01) P[n0 + __popcll(m1 & below)] = make_uint4(o_rt, as_u(wrt), lane, 0u);
+            if (f & kB11) P[n0 + n1 + __popcll(m2 & below)] = make_uint4(o_rb, as_u(wrb), lane, 0u);
+            if (f & kB10) P[n0 + n1 + n2 + __popcll(m3 & below)] = make_uint4(o_lb, as_u(wlb), lane, 0u);
         }
         // stage the [32 ch][64 bin] slice of top_diff
         {
@@ -799,32 +816,19 @@ __global__ __launch_bounds__(kWave) void rroi_bwd_tiled_kernel(
                 *reinterpret_cast<v4f*>(T + r * kTStride + (col ^ ((r >> 3) * 4u))) = v;
             }
         }
-        __syncthreads();
+        lds_wave_sync();
 
-        float* gp = gcm + ((size_t)(batch_ok ? A.batch : 0) * nchunks + k) * ((size_t)slice_px * kChunk) + q * 4;
-#pragma unroll
-        for (int it = 0; it < kIters; ++it) {
-            const uint4 u = G[it * kBinsPerIter + b];
-            const unsigned f = u.y;
-            float wlt, wrt, wrb, wlb;
-            tap_weights(as_f(u.z), as_f(u.w), wlt, wrt, wrb, wlb);
-            const float* tr = T + (q * 4) * kTStride + ((it * kBinsPerIter + b) ^ wswz);
-            const unsigned o_lt = u.x;
-            const unsigned o_rt = o_lt + ((f & kDx) ? (unsigned)kChunk : 0u);
-            const unsigned o_lb = o_lt + ((f & kDy) ? (unsigned)pitch * kChunk : 0u);
-            const unsigned o_rb = o_lb + ((f & kDx) ? (unsigned)kChunk : 0u);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if ((unsigned)j >= cvalid) break;
-                const float gval = tr[j * kTStride];
-                // kernel.cu:260-274: v1..v4 = w * top_diff, four independent atomicAdds
-                if (f & kB00) unsafeAtomicAdd(gp + o_lt + j, wlt * gval);
-                if (f & kB01) unsafeAtomicAdd(gp + o_rt + j, wrt * gval);
-                if (f & kB11) unsafeAtomicAdd(gp + o_rb + j, wrb * gval);
-                if (f & kB10) unsafeAtomicAdd(gp + o_lb + j, wlb * gval);
-            }
+        // scatter: two list entries per atomic instruction, 32 consecutive floats each
+        float* gp = gcm + ((size_t)(batch_ok ? A.batch : 0) * nchunks + k) * ((size_t)slice_px * kChunk) + c;
+        const float* trow = T + c * kTStride;
+        const unsigned cswz = (c >> 3) * 4u;
+        for (unsigned i = half; i < npairs; i += 2) {
+            const uint4 e = P[i];
+            // kernel.cu:260-263: v_k = w_k * top_diff_of_bin, one fp32 multiply
+            const float contrib = as_f(e.y) * trow[e.z ^ cswz];
+            if (c_ok) unsafeAtomicAdd(gp + e.x, contrib);
         }
-        __syncthreads();
+        lds_wave_sync();
     }
 }
 
