@@ -21,10 +21,13 @@
  * build's recipe for both oracle and HIP kernel is the correctly-rounded-in-
  * practice (float)cos((double)angle), (float)sin((double)angle).
  *
- * Pinning: the restatement is checked against the only outputs of the real
- * CUDA op the reference holds (rroi_align/data/res{0,1,2}.jpg, grad.jpg
- * written by rroi_align/test2.py:87,98) in tests/test_oracle_kat.py, and
- * against an independent numpy restatement (oracle/rroi_align_oracle.py).
+ * Pinning: (1) tests/test_oracle_kat.py -- the only outputs of the real CUDA op
+ * the reference holds (rroi_align/data/res{0,1,2}.jpg, grad.jpg written by
+ * rroi_align/test2.py:87,98); (2) tests/test_oracle_refhip.py -- outputs of the
+ * reference's own kernels (rroi_align_kernel.cu through ROCm's hipify-perl,
+ * oracle/Makefile: ref) run on an MI355X, reproduced bit for bit (forward,
+ * con_idx_x/y); (3) an independent numpy restatement
+ * (oracle/rroi_align_oracle.py) that must agree bit for bit.
  */
 #include <math.h>
 #include <stdint.h>
