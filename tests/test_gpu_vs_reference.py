@@ -1,0 +1,78 @@
+"""GPU (MI355X): our op next to the REFERENCE'S OWN KERNELS on the same device.
+
+oracle/_ref/librroi_ref_hip.so is rroi_align_kernel.cu (forward :28-162, backward :193-278, with
+its launchers) run through ROCm's hipify-perl and compiled by hipcc (oracle/Makefile: ref).  It is
+built where /root/reference exists and travels to the GPU box as a binary; these tests skip when
+it is absent.  The host side reproduces functions/rroi_align.py:13-40 (zero-filled buffers)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import workloads as Wk
+
+pytestmark = pytest.mark.gpu
+
+REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref",
+                   "librroi_ref_hip.so")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    lib = ctypes.CDLL(REF)
+    vp, fl, it = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
+    lib.RROIAlignForwardLaucher.argtypes = [vp, fl, it, it, it, it, it, it, vp, vp, vp, vp, vp]
+    lib.RROIAlignBackwardLaucher.argtypes = [vp, fl, it, it, it, it, it, it, it, vp, vp, vp, vp, vp]
+    return lib
+
+
+def ref_forward(lib, F, R, ph, pw, scale):
+    n, (B, C, H, W) = R.shape[0], F.shape
+    out, ix, iy = (torch.zeros((n, C, ph, pw), device="cuda") for _ in range(3))
+    lib.RROIAlignForwardLaucher(F.data_ptr(), scale, n, H, W, C, ph, pw, R.data_ptr(), out.data_ptr(),
+                                ix.data_ptr(), iy.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return out, ix, iy
+
+
+@pytest.mark.parametrize("case", ["cfg2_full", "train_like", "image_like"])
+def test_forward_identical_to_reference_kernel(ref, case):
+    from rroi_align._ext import rroi_align as ext
+    if case == "cfg2_full":      # BASELINE configs[1]
+        f, r = Wk.bench_inputs()
+        ph, pw, s = 8, 64, 0.25
+    elif case == "train_like":   # src/ocr_process.py:259-267 regime
+        f, r = Wk.bench_inputs(R=32, C=64, H=120, W=160, img=640, seed=5, batch=2)
+        ph, pw, s = 11, 83, 0.25
+    else:                        # rroi_align/test2.py regime: image as the map, 44 x 349
+        f, r = Wk.bench_inputs(R=3, C=3, H=276, W=500, img=500, seed=6)
+        ph, pw, s = 44, 349, 1.0
+    F, R = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
+    want, ix, iy = ref_forward(ref, F, R, ph, pw, s)
+    for path in (ext.PATH_TILED, ext.PATH_DIRECT):
+        got = ext.forward(F, R, ph, pw, s, path=path)
+        ndiff = int((got != want).sum())
+        assert ndiff == 0, f"{case} path {path}: {ndiff} of {got.numel()} elements differ from the reference kernel"
+    # the reference-ABI entry point of this library fills con_idx_x / con_idx_y identically
+    out2, ix2, iy2 = (torch.empty_like(want) for _ in range(3))
+    assert ext.rroi_align_forward_cuda(ph, pw, s, F, R, out2, ix2, iy2) == 1
+    assert torch.equal(out2, want) and torch.equal(ix2, ix) and torch.equal(iy2, iy)
+
+
+def test_backward_matches_reference_kernel(ref):
+    from rroi_align._ext import rroi_align as ext
+    f, r = Wk.bench_inputs(R=128, C=64, seed=21)
+    F, R = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
+    out, ix, iy = ref_forward(ref, F, R, 8, 64, 0.25)
+    gout = torch.randn_like(out)
+    want = torch.zeros_like(F)
+    ref.RROIAlignBackwardLaucher(gout.data_ptr(), 0.25, 1, 128, 160, 160, 64, 8, 64, R.data_ptr(),
+                                 want.data_ptr(), ix.data_ptr(), iy.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+    scale = float(want.abs().max())
+    for path in (ext.PATH_TILED, ext.PATH_DIRECT):
+        got = ext.backward(gout, R, f.shape, 0.25, path=path)
+        assert float((got - want).abs().max()) <= 1e-4 * scale
