@@ -249,8 +249,11 @@ __device__ __forceinline__ v4f buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_
 }
 // Cache policy of the output stream (gfx940-family bits: 1 = sc0, 2 = nt, 16 = sc1).  The
 // 256 MiB of crops must not displace the 3.3 MB map slice from the XCD's 4 MiB L2: with plain
-// stores every written line is kept in L2 and 47 % of the tap reads missed L2; sc1 stores
-// are written through and dropped.
+// stores every written line is kept in L2 and 47 % of the tap reads missed L2 (gather kernel
+// 61 us).  Both nt (streaming) and sc1 (write-through, line dropped) avoid that: 52.4 / 50.6 us
+// for the kernel alone -- but in the prologue+gather sequence the step takes 60 us with nt
+// against 67 us with sc1 (the write-through traffic is still draining when the next prologue
+// starts), so nt is the default.
 template <int AUX>
 __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned byte_off, v4f v)
 {
@@ -1108,7 +1111,7 @@ bool pick_tiled(int batch_size, int channels, int height, int width, int num_roi
     return out_elems >= 2.0 * map_elems;
 }
 
-int g_store_aux = 16;  // exploration knob: cache policy of the output stores
+int g_store_aux = 2;   // cache policy of the output stores (see buf_store); 16 / 0 for exploration
 int g_fwd_dbg = 0;     // ablation: 1 = skip output stores, 2 = all taps out of range
 int g_prologue_blocks_per_cu = 3;
 int g_prologue_aux = 0;
@@ -1239,10 +1242,10 @@ int rroi_align_forward_stages_hip(const float* features, int feature_layout, flo
     hipLaunchKernelGGL((rroi_fwd_tiled_kernel<VEC, AUX>), dim3(grid), dim3(kWave), 0, stream, map,   \
                        ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,        \
                        batch_size, nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
-        if (NB % 4 != 0) RROI_LAUNCH_FWD(false, 16);
-        else if (g_store_aux == 0) RROI_LAUNCH_FWD(true, 0);   // exploration only
-        else if (g_store_aux == 2) RROI_LAUNCH_FWD(true, 2);   // exploration only
-        else RROI_LAUNCH_FWD(true, 16);
+        if (NB % 4 != 0) RROI_LAUNCH_FWD(false, 2);
+        else if (g_store_aux == 0) RROI_LAUNCH_FWD(true, 0);    // exploration only
+        else if (g_store_aux == 16) RROI_LAUNCH_FWD(true, 16);  // exploration only
+        else RROI_LAUNCH_FWD(true, 2);
 #undef RROI_LAUNCH_FWD
     }
     return launch_status();
