@@ -88,12 +88,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # RROI_BENCH_ONE_DEVICE=1 (self-test only): all ranks share cuda:0 and rendezvous over gloo, so
+    # the multi-rank code path can be exercised on a one-GPU box.  Never set by the driver.
+    one_device = os.environ.get("RROI_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     from rroi_align._ext import rroi_align as ext  # fails loudly if the HIP library is missing
     from rroi_align.sharded import shard_bounds
@@ -134,7 +142,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

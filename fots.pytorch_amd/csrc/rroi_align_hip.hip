@@ -474,7 +474,9 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         const bool hi = dx && dy, lo = active && !hi;
         const unsigned long long m_lo = __ballot(lo), m_hi = __ballot(hi);
         const unsigned n_lo = __popcll(m_lo), n_hi = __popcll(m_hi);
-        n_lo_groups = (n_lo + kBinsPerIter - 1) / kBinsPerIter;
+        // at least one LO group (all padding if need be): its loads are issued unconditionally,
+        // one item ahead, before the previous item's stores
+        n_lo_groups = n_lo ? (n_lo + kBinsPerIter - 1) / kBinsPerIter : 1u;
         n_hi_groups = (n_hi + kBinsPerIter - 1) / kBinsPerIter;
         amask = m_lo | m_hi;
         const unsigned hi_base = n_lo_groups * kBinsPerIter;
@@ -568,6 +570,38 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     auto pin_lo = [&](int s) { asm volatile("" : "+v"(lt[s]), "+v"(rt[s])); };
     auto pin_hi = [&](int s) { asm volatile("" : "+v"(lt[s]), "+v"(rt[s]), "+v"(lb[s]), "+v"(rbv[s])); };
 
+    // phase C of one item: [rows < C] x [64 bins] -> 256-byte row segments
+    auto store_tile = [&](unsigned n, unsigned t, unsigned long long cur_mask) {
+        if (dbg & 1) return;  // (ablation knob: dbg & 1 skips the output stores)
+        // descriptor over this (roi, chunk) block of the output: rows >= C fall out of range
+        float* obase = out + ((size_t)n * C + k * kChunk) * NB;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, chans_here * (unsigned)NB * 4u);
+        const unsigned bin0 = t * kTileBins + col;
+        // bins that were in no group (masked by pw > roi_pooled_width) are zero
+        const unsigned nib = (unsigned)(cur_mask >> col) & 15u;
+        const bool a0 = nib & 1u, a1 = nib & 2u, a2 = nib & 4u, a3 = nib & 8u;
+        v4f v[kChunk / 4];
+#pragma unroll
+        for (int s = 0; s < kChunk / 4; ++s) {
+            const unsigned r = s * 4 + row0;
+            v[s] = *reinterpret_cast<const v4f*>(T + r * kTStride + (col ^ ((r >> 3) * 4u)));
+        }
+#pragma unroll
+        for (int s = 0; s < kChunk / 4; ++s) {
+            const unsigned r = s * 4 + row0;
+            const unsigned off = (r * (unsigned)NB + bin0) * 4u;
+            const v4f o = {a0 ? v[s].x : 0.f, a1 ? v[s].y : 0.f, a2 ? v[s].z : 0.f, a3 ? v[s].w : 0.f};
+            if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
+                buf_store<AUX>(ws, bin0 < (unsigned)NB ? off : kOOB, o);
+            } else {
+                buf_store1<AUX>(ws, bin0 + 0 < (unsigned)NB ? off + 0 : kOOB, o.x);
+                buf_store1<AUX>(ws, bin0 + 1 < (unsigned)NB ? off + 4 : kOOB, o.y);
+                buf_store1<AUX>(ws, bin0 + 2 < (unsigned)NB ? off + 8 : kOOB, o.z);
+                buf_store1<AUX>(ws, bin0 + 3 < (unsigned)NB ? off + 12 : kOOB, o.w);
+            }
+        }
+    };
+
     unsigned item = slot;
     if (item >= items) return;
     unsigned n = fdiv(item, div_tiles);
@@ -576,6 +610,8 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     geometry(A, t, g_lo, g_hi, act_mask);
     lds_wave_sync();
     __amdgpu_buffer_rsrc_t rs = slice_rsrc(A);
+    fetch(0, 0);
+    issue_lo(rs, 0);  // LO group 0 of the first item
 
     for (;;) {
         const unsigned item_next = item + nslots;
@@ -584,28 +620,24 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         const unsigned t_next = item_next - n_next * (unsigned)ntiles;
         const Affine A_next = aff[n_next];  // in flight during phase B
 
-        // ---- phase B: LO groups, then HI groups; the loads of group g+1 are issued before
-        // group g is blended.  The loops are unrolled with an early exit, and the two exit
-        // paths end in different (empty) asm statements so that the compiler cannot merge
-        // their tails: each blend then has ONE predecessor and its s_waitcnt knows exactly
-        // how many younger loads are in flight.
-        if (g_lo > 0) {
-            fetch(0, 0);
-            issue_lo(rs, 0);
+        // ---- phase B: LO groups (group 0 is already in flight), then HI groups; the loads of
+        // group g+1 are issued before group g is blended.  The loops are unrolled with an early
+        // exit, and the two exit paths end in different (empty) asm statements so that the
+        // compiler cannot merge their tails: each blend then has ONE predecessor and its
+        // s_waitcnt knows exactly how many younger loads are in flight.
 #pragma unroll
-            for (int it = 0; it < kIters; ++it) {
-                const int s = it & 1;
-                if ((unsigned)(it + 1) < g_lo) {
-                    fetch(it + 1, s ^ 1);
-                    issue_lo(rs, s ^ 1);
-                    pin_lo(s);
-                    blend_lo(s);
-                    asm volatile("; lo: more groups follow");
-                } else {
-                    blend_lo(s);
-                    asm volatile("; lo: last group");
-                    break;
-                }
+        for (int it = 0; it < kIters; ++it) {
+            const int s = it & 1;
+            if ((unsigned)(it + 1) < g_lo) {
+                fetch(it + 1, s ^ 1);
+                issue_lo(rs, s ^ 1);
+                pin_lo(s);
+                blend_lo(s);
+                asm volatile("; lo: more groups follow");
+            } else {
+                blend_lo(s);
+                asm volatile("; lo: last group");
+                break;
             }
         }
         if (g_hi > 0) {
@@ -628,52 +660,25 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
             }
         }
         const unsigned long long cur_mask = act_mask;
-        // every record of this item has been fetched: G is free for the next item
-        lds_wave_sync();
-        __amdgpu_buffer_rsrc_t rs_next = rs;
-        if (has_next) {
-            geometry(A_next, t_next, g_lo, g_hi, act_mask);
-            rs_next = slice_rsrc(A_next);
+        lds_wave_sync();  // T complete; every record of this item has been fetched: G is free
+        if (!has_next) {
+            store_tile(n, t, cur_mask);
+            break;
         }
+        // The next item's records are built and its first loads issued BEFORE this item's
+        // stores: gfx950 has one in-order counter for loads and stores, so a load issued after
+        // the stores could not be consumed before they are acknowledged by the memory system.
+        geometry(A_next, t_next, g_lo, g_hi, act_mask);
         lds_wave_sync();
-
-        // ---- phase C of the current item: [rows < C] x [64 bins] -> 256-byte row segments ----
-        if (!(dbg & 1)) {  // (ablation knob: dbg & 1 skips the output stores)
-            // descriptor over this (roi, chunk) block of the output: rows >= C fall out of range
-            float* obase = out + ((size_t)n * C + k * kChunk) * NB;
-            const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, chans_here * (unsigned)NB * 4u);
-            const unsigned bin0 = t * kTileBins + col;
-            // bins that were in no group (masked by pw > roi_pooled_width) are zero
-            const unsigned nib = (unsigned)(cur_mask >> col) & 15u;
-            const bool a0 = nib & 1u, a1 = nib & 2u, a2 = nib & 4u, a3 = nib & 8u;
-            v4f v[kChunk / 4];
-#pragma unroll
-            for (int s = 0; s < kChunk / 4; ++s) {
-                const unsigned r = s * 4 + row0;
-                v[s] = *reinterpret_cast<const v4f*>(T + r * kTStride + (col ^ ((r >> 3) * 4u)));
-            }
-#pragma unroll
-            for (int s = 0; s < kChunk / 4; ++s) {
-                const unsigned r = s * 4 + row0;
-                const unsigned off = (r * (unsigned)NB + bin0) * 4u;
-                const v4f o = {a0 ? v[s].x : 0.f, a1 ? v[s].y : 0.f, a2 ? v[s].z : 0.f, a3 ? v[s].w : 0.f};
-                if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
-                    buf_store<AUX>(ws, bin0 < (unsigned)NB ? off : kOOB, o);
-                } else {
-                    buf_store1<AUX>(ws, bin0 + 0 < (unsigned)NB ? off + 0 : kOOB, o.x);
-                    buf_store1<AUX>(ws, bin0 + 1 < (unsigned)NB ? off + 4 : kOOB, o.y);
-                    buf_store1<AUX>(ws, bin0 + 2 < (unsigned)NB ? off + 8 : kOOB, o.z);
-                    buf_store1<AUX>(ws, bin0 + 3 < (unsigned)NB ? off + 12 : kOOB, o.w);
-                }
-            }
-        }
+        rs = slice_rsrc(A_next);
+        fetch(0, 0);
+        issue_lo(rs, 0);
+        store_tile(n, t, cur_mask);
         lds_wave_sync();
-        if (!has_next) break;
         item = item_next;
         n = n_next;
         t = t_next;
         A = A_next;
-        rs = rs_next;
     }
 }
 
