@@ -961,6 +961,57 @@ __global__ __launch_bounds__(256) void rroi_bwd_literal_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Callers' side of the path: detected / annotated quads -> the op's
+// (R, 6) ROI rows, on the device, for a whole image batch at once -- so that inference can
+// issue ONE RoIRotate launch per image instead of one per word (tools/ocr_utils.py:131-177).
+//   mode 0  tools/ocr_utils.py:133-150: fp32 edge vectors, fp32 squared length, sqrt and atan2 in
+//           double, centre truncated to int, angle of edge 1->2
+//   mode 1  src/ocr_process.py:196-206: everything in double, angle = mean of edges 1->2 and 0->3
+// Also emits each box's pooled width by the inference rule (ocr_utils.py:147-150).
+// ------------------------------------------------------------------------------------
+__global__ void rroi_quads_to_rois_kernel(const float* __restrict__ quads, const float* __restrict__ bidx,
+                                          int n, int mode, int target_h, float* __restrict__ rois,
+                                          int* __restrict__ gw)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* b = quads + (size_t)i * 8;
+    const float x0 = b[0], y0 = b[1], x1 = b[2], y1 = b[3], x2 = b[4], y2 = b[5], x3 = b[6], y3 = b[7];
+    double w, h, angle, cx, cy;
+    if (mode == 0) {
+        const float ccx = (((x0 + x1) + x2) + x3) / 4.0f, ccy = (((y0 + y1) + y2) + y3) / 4.0f;
+        const float dwx = x2 - x1, dwy = y2 - y1, dhx = x1 - x0, dhy = y1 - y0;
+        w = sqrt((double)((dwx * dwx) + (dwy * dwy)));
+        h = sqrt((double)((dhx * dhx) + (dhy * dhy)));
+        angle = atan2((double)(y2 - y1), (double)(x2 - x1));
+        cx = (double)(int)ccx;  // int(center[0]): truncation toward zero
+        cy = (double)(int)ccy;
+    } else {
+        const double X0 = x0, Y0 = y0, X1 = x1, Y1 = y1, X2 = x2, Y2 = y2, X3 = x3, Y3 = y3;
+        cx = (((X0 + X1) + X2) + X3) / 4.0;
+        cy = (((Y0 + Y1) + Y2) + Y3) / 4.0;
+        const double dwx = X2 - X1, dwy = Y2 - Y1, dhx = X1 - X0, dhy = Y1 - Y0;
+        w = sqrt(dwx * dwx + dwy * dwy);
+        h = sqrt(dhx * dhx + dhy * dhy);
+        angle = (atan2(Y2 - Y1, X2 - X1) + atan2(Y3 - Y0, X3 - X0)) / 2.0;
+    }
+    angle = -angle / 3.1415926535 * 180.0;
+    float* r = rois + (size_t)i * 6;
+    r[0] = bidx ? bidx[i] : 0.0f;
+    r[1] = (float)cx;
+    r[2] = (float)cy;
+    r[3] = (float)h;
+    r[4] = (float)w;
+    r[5] = (float)angle;
+    if (gw) {
+        const double scale = (double)target_h / (h > 1.0 ? h : 1.0);  // max(1, h)
+        const int t = (int)(w * scale) + target_h;
+        const int g = t / 32;  // t >= target_h > 0: floor division == truncation
+        gw[i] = (g > 2 ? g : 2) * 32;
+    }
+}
+
 __global__ void rroi_bin_centres_kernel(const float* __restrict__ rois, float* __restrict__ geom,
                                         int num_rois, int height, int width, int pooled_height,
                                         int pooled_width, float spatial_scale)
@@ -1370,6 +1421,18 @@ int rroi_align_bin_centres_hip(float spatial_scale, int num_rois, int height, in
     hipLaunchKernelGGL(rroi_bin_centres_kernel, dim3(ceil_div(threads, 256)), dim3(256), 0, stream,
                        rois, geom, num_rois, height, width, pooled_height, pooled_width,
                        spatial_scale);
+    return launch_status();
+}
+
+int rroi_align_quads_to_rois_hip(const float* quads, const float* batch_index, int n, int mode,
+                                 int target_h, float* rois, int* target_gw, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n < 0 || (mode != 0 && mode != 1) || target_h <= 0) return 0;
+    if (n == 0) return 1;
+    if (!quads || !rois) return 0;
+    hipLaunchKernelGGL(rroi_quads_to_rois_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, quads,
+                       batch_index, n, mode, target_h, rois, target_gw);
     return launch_status();
 }
 

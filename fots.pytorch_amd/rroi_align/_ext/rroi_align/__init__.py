@@ -47,6 +47,8 @@ _lib.rroi_align_backward_hip.restype = _i
 _lib.rroi_align_backward_hip.argtypes = [_vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]
 _lib.rroi_align_bin_centres_hip.restype = _i
 _lib.rroi_align_bin_centres_hip.argtypes = [_f, _i, _i, _i, _i, _i, _vp, _vp, _vp]
+_lib.rroi_align_quads_to_rois_hip.restype = _i
+_lib.rroi_align_quads_to_rois_hip.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]
 _lib.rroi_align_sincos_probe_hip.restype = _i
 _lib.rroi_align_sincos_probe_hip.argtypes = [_vp, _i, _vp, _vp]
 _lib.RROIAlignForwardLaucher.restype = _i
@@ -58,7 +60,7 @@ EXPORTS = (
     "RROIAlignForwardLaucher", "RROIAlignBackwardLaucher", "rroi_align_forward_hip",
     "rroi_align_backward_hip", "rroi_align_forward_stages_hip", "rroi_align_forward_workspace_bytes",
     "rroi_align_backward_workspace_bytes", "rroi_align_bin_centres_hip",
-    "rroi_align_sincos_probe_hip", "rroi_align_hip_version",
+    "rroi_align_sincos_probe_hip", "rroi_align_quads_to_rois_hip", "rroi_align_hip_version",
 )
 
 
@@ -164,6 +166,27 @@ def bin_centres(rois: torch.Tensor, pooled_height: int, pooled_width: int, spati
                                              rois.data_ptr(), geom.data_ptr(), _stream())
     _check(st, "rroi_align_bin_centres_hip")
     return geom
+
+
+def quads_to_rois(quads: torch.Tensor, batch_index=None, mode: int = 0, target_h: int = 11):
+    """(N, 8) quads -> ((N, 6) rois, (N,) int32 pooled widths), both on the device."""
+    _require_cuda_f32(quads, "quads")
+    quads = quads.contiguous().view(-1, 8)
+    n = quads.size(0)
+    if batch_index is not None:
+        _require_cuda_f32(batch_index, "batch_index")
+        batch_index = batch_index.contiguous().view(-1)
+        if batch_index.numel() != n:
+            raise ValueError("batch_index must have one entry per quad")
+    with torch.cuda.device_of(quads):
+        rois = torch.empty((n, 6), dtype=torch.float32, device=quads.device)
+        gw = torch.empty((n,), dtype=torch.int32, device=quads.device)
+        st = _lib.rroi_align_quads_to_rois_hip(quads.data_ptr(),
+                                               batch_index.data_ptr() if batch_index is not None else None,
+                                               n, int(mode), int(target_h), rois.data_ptr(), gw.data_ptr(),
+                                               _stream())
+    _check(st, "rroi_align_quads_to_rois_hip")
+    return rois, gw
 
 
 def sincos_probe(angle_deg: torch.Tensor) -> torch.Tensor:

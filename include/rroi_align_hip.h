@@ -107,6 +107,18 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
                             float* bottom_diff, void* workspace, size_t workspace_bytes, int path,
                             void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * 3. The callers' ROI construction, on the device.
+ *    quads (n, 8) fp32 [x0,y0,x1,y1,x2,y2,x3,y3] -> rois (n, 6) fp32 rows for the
+ *    op, plus (optionally) each box's pooled width by the inference rule.
+ *      mode 0 replaces tools/ocr_utils.py:133-150 (align_ocr, per detected box)
+ *      mode 1 replaces src/ocr_process.py:196-206 (ground-truth quads in training;
+ *             the random height jitter of :204 stays with the caller)
+ *    batch_index (n) fp32 may be NULL (= 0).  target_gw (n) int32 may be NULL.
+ * ------------------------------------------------------------------------- */
+int rroi_align_quads_to_rois_hip(const float* quads, const float* batch_index, int n, int mode,
+                                 int target_h, float* rois, int* target_gw, void* stream);
+
 /* Bin centres only: geom (R, PH, PW, 2) = (bin_cx, bin_cy), 0 where the bin is
  * outside the ROI's pooled width (kernel.cu:86-107).  Diagnostic / test hook. */
 int rroi_align_bin_centres_hip(float spatial_scale, int num_rois, int height, int width,

@@ -1,0 +1,100 @@
+"""Callers' ROI construction: CPU checks of the restatement,
+GPU parity of the device kernel, and the batched launch against per-box launches."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import roi_build_oracle as RB
+
+
+def random_quads(n, seed=0, integer=False, size=(1280, 704)):
+    """Rotated rectangles as 4 corner points, order 0..3 = bl, tl, tr, br of the text box as in
+    rroi_align/test2.py:42-46 (edge 1->2 is the long 'width' edge, 0->1 the 'height' edge)."""
+    rng = np.random.default_rng(seed)
+    q = np.zeros((n, 4, 2))
+    for i in range(n):
+        cx, cy = rng.uniform(100, size[0] - 100), rng.uniform(100, size[1] - 100)
+        h, w = rng.uniform(12, 60), rng.uniform(40, 400)
+        a = rng.uniform(-80, 80) / 180 * math.pi
+        ux, uy = math.cos(a), math.sin(a)        # along the text
+        vx, vy = -math.sin(a), math.cos(a)       # down
+        q[i, 0] = (cx - ux * w / 2 + vx * h / 2, cy - uy * w / 2 + vy * h / 2)
+        q[i, 1] = (cx - ux * w / 2 - vx * h / 2, cy - uy * w / 2 - vy * h / 2)
+        q[i, 2] = (cx + ux * w / 2 - vx * h / 2, cy + uy * w / 2 - vy * h / 2)
+        q[i, 3] = (cx + ux * w / 2 + vx * h / 2, cy + uy * w / 2 + vy * h / 2)
+    if integer:
+        q = np.round(q)
+    return q.reshape(n, 8).astype(np.float32)
+
+
+def test_restatement_on_the_reference_demo_quad():
+    """rroi_align/test2.py:43 quad gt2 -> the numbers its own code (test2.py:50-61) produces."""
+    gt = np.asarray([[206, 111], [199, 95], [349, 60], [355, 80]], np.float32)
+    rois, gw = RB.rois_from_quads(gt.reshape(1, 8), mode=1)
+    center = gt.sum(0) / 4
+    w = math.sqrt(150 ** 2 + 35 ** 2)
+    h = math.sqrt(7 ** 2 + 16 ** 2)
+    ang = -(math.atan2(-35, 150) + math.atan2(-31, 149)) / 2 / 3.1415926535 * 180
+    want = np.asarray([0, center[0], center[1], h, w, ang], np.float64).astype(np.float32)
+    assert np.array_equal(rois[0], want)
+    # inference flavour: truncated centre, single-edge angle, width rule of ocr_utils.py:147-150
+    r0, g0 = RB.rois_from_quads(gt.reshape(1, 8), mode=0)
+    assert r0[0, 1] == 277.0 and r0[0, 2] == 86.0
+    assert np.float32(-math.atan2(-35, 150) / 3.1415926535 * 180) == r0[0, 5]
+    assert g0[0] == max(2, (int(w * (11 / h)) + 11) // 32) * 32 == 96
+
+
+def test_pooled_width_rules():
+    q = random_quads(64, seed=3)
+    rois, gw = RB.rois_from_quads(q, mode=0)
+    assert (gw % 32 == 0).all() and (gw >= 64).all()
+    # the rule rounds DOWN to a multiple of 32: it may cut a crop (gw < roi_pooled_width = 11*w/h,
+    # kernel.cu:68) but never by more than 32 - 11 columns
+    rpw = 11 * rois[:, 4] / np.maximum(rois[:, 3], 1)
+    assert (gw > rpw - 21).all() and ((gw == 64) | (gw <= rpw + 11)).all()
+    assert RB.train_pooled_width(rois) == math.ceil(11 * float((rois[:, 4] / rois[:, 3]).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_device_roi_builder_matches_restatement(mode):
+    from rroi_align._ext import rroi_align as ext
+    for integer in (True, False):
+        q = random_quads(2000, seed=11 + mode, integer=integer)
+        bidx = (np.arange(2000) % 4).astype(np.float32)
+        want, wgw = RB.rois_from_quads(q, bidx, mode=mode)
+        got, ggw = ext.quads_to_rois(torch.from_numpy(q).cuda(), torch.from_numpy(bidx).cuda(), mode)
+        got, ggw = got.cpu().numpy(), ggw.cpu().numpy()
+        # fp64 sqrt is correctly rounded on both sides; atan2 comes from ocml vs glibc: equal after
+        # rounding to fp32 except for at most a last-place difference in the angle
+        assert np.array_equal(got[:, :5], want[:, :5])
+        ulp = np.abs(got[:, 5].view(np.int32) - want[:, 5].view(np.int32))
+        assert ulp.max() <= 1 and (ulp != 0).mean() < 1e-3
+        assert np.array_equal(ggw, wgw)
+
+
+@pytest.mark.gpu
+def test_batched_launch_equals_per_box_launches(oracle):
+    """One launch for all boxes of an image == the reference's loop of R = 1 launches
+    (tools/ocr_utils.py:147-177): identical on each box's own width target_gw[i].  Beyond it the
+    batched crop continues up to the box's roi_pooled_width (the per-box width rounds down to a
+    multiple of 32 and may cut the word) and is zero after that (kernel.cu:107)."""
+    from rroi_align.batched import BatchedRRoiAlign
+    from rroi_align.modules.rroi_align import _RRoiAlign
+    rng = np.random.default_rng(5)
+    feats_np = rng.standard_normal((1, 64, 176, 320), dtype=np.float32)   # focr: 64 ch at 1/4 of 1280x704
+    feats = torch.from_numpy(feats_np).cuda()
+    q = random_quads(24, seed=7)
+    crops, gw = BatchedRRoiAlign(11, 1.0 / 4)(feats, torch.from_numpy(q).cuda())
+    rois, wgw = RB.rois_from_quads(q, mode=0)
+    assert crops.shape == (24, 64, 11, int(wgw.max()))
+    for i in range(24):
+        single = _RRoiAlign(11, int(wgw[i]), 1.0 / 4)(feats, torch.from_numpy(rois[i:i + 1]).cuda())
+        assert torch.equal(crops[i:i + 1, :, :, :int(wgw[i])], single)
+        rpw = 11 * rois[i, 4] / rois[i, 3]
+        assert not crops[i, :, :, int(math.floor(rpw)) + 1:].any()
+    # and against the oracle, element for element
+    want = oracle.forward_c(feats_np, rois, 11, int(wgw.max()), 0.25, threads=4)
+    assert np.array_equal(crops.cpu().numpy(), want)

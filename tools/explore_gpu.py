@@ -87,6 +87,35 @@ for name, (Rn, C, H, W, ph, pw) in {"infer_R1_c64_11x64": (1, 64, 176, 320, 11, 
     for pname, pth in (("direct", ext.PATH_DIRECT), ("tiled", ext.PATH_TILED)):
         res[f"{name}_{pname}"] = timeit(lambda: ext.forward(Ft, Rt, ph, pw, 0.25, path=pth), iters=30)
 
+# --- inference: one launch per word (tools/ocr_utils.py:131-177) vs one per image ---------------
+from rroi_align.batched import BatchedRRoiAlign  # noqa: E402
+from rroi_align.modules.rroi_align import _RRoiAlign  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_roi_build import random_quads  # noqa: E402
+from oracle import roi_build_oracle as RB  # noqa: E402  (host-side restatement = what the reference does per box)
+focr = torch.randn(1, 64, 176, 320, device=dev)
+quads_np = random_quads(24, seed=7)
+quads = torch.from_numpy(quads_np).to(dev)
+batched = BatchedRRoiAlign(11, 0.25)
+
+
+def per_box_loop():
+    outs = []
+    for i in range(24):  # host numpy ROI, upload, R = 1 launch -- the reference's structure
+        roi, gwi = RB.rois_from_quads(quads_np[i:i + 1], mode=0)
+        outs.append(_RRoiAlign(11, int(gwi[0]), 0.25)(focr, torch.from_numpy(roi).to(dev)))
+    return outs
+
+
+import time  # noqa: E402
+for name, fn in (("infer_24_boxes_per_box_loop", per_box_loop), ("infer_24_boxes_batched", lambda: batched(focr, quads))):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    res[name] = {"wall_us_per_image": (time.perf_counter() - t0) / 20 * 1e6}
+
 # --- the reference's own kernels (oracle/_ref) --------------------------------------------
 ref_path = os.path.join(ROOT, "oracle", "_ref", "librroi_ref_hip.so")
 if os.path.exists(ref_path):
