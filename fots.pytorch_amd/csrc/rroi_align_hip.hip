@@ -580,24 +580,28 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         // bins that were in no group (masked by pw > roi_pooled_width) are zero
         const unsigned nib = (unsigned)(cur_mask >> col) & 15u;
         const bool a0 = nib & 1u, a1 = nib & 2u, a2 = nib & 4u, a3 = nib & 8u;
-        v4f v[kChunk / 4];
+        // two halves of 4 row groups: 16 instead of 32 registers live across the LDS reads
 #pragma unroll
-        for (int s = 0; s < kChunk / 4; ++s) {
-            const unsigned r = s * 4 + row0;
-            v[s] = *reinterpret_cast<const v4f*>(T + r * kTStride + (col ^ ((r >> 3) * 4u)));
-        }
+        for (int hs = 0; hs < 2; ++hs) {
+            v4f v[kChunk / 8];
 #pragma unroll
-        for (int s = 0; s < kChunk / 4; ++s) {
-            const unsigned r = s * 4 + row0;
-            const unsigned off = (r * (unsigned)NB + bin0) * 4u;
-            const v4f o = {a0 ? v[s].x : 0.f, a1 ? v[s].y : 0.f, a2 ? v[s].z : 0.f, a3 ? v[s].w : 0.f};
-            if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
-                buf_store<AUX>(ws, bin0 < (unsigned)NB ? off : kOOB, o);
-            } else {
-                buf_store1<AUX>(ws, bin0 + 0 < (unsigned)NB ? off + 0 : kOOB, o.x);
-                buf_store1<AUX>(ws, bin0 + 1 < (unsigned)NB ? off + 4 : kOOB, o.y);
-                buf_store1<AUX>(ws, bin0 + 2 < (unsigned)NB ? off + 8 : kOOB, o.z);
-                buf_store1<AUX>(ws, bin0 + 3 < (unsigned)NB ? off + 12 : kOOB, o.w);
+            for (int s4 = 0; s4 < kChunk / 8; ++s4) {
+                const unsigned r = (hs * (kChunk / 8) + s4) * 4 + row0;
+                v[s4] = *reinterpret_cast<const v4f*>(T + r * kTStride + (col ^ ((r >> 3) * 4u)));
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < kChunk / 8; ++s4) {
+                const unsigned r = (hs * (kChunk / 8) + s4) * 4 + row0;
+                const unsigned off = (r * (unsigned)NB + bin0) * 4u;
+                const v4f o = {a0 ? v[s4].x : 0.f, a1 ? v[s4].y : 0.f, a2 ? v[s4].z : 0.f, a3 ? v[s4].w : 0.f};
+                if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
+                    buf_store<AUX>(ws, bin0 < (unsigned)NB ? off : kOOB, o);
+                } else {
+                    buf_store1<AUX>(ws, bin0 + 0 < (unsigned)NB ? off + 0 : kOOB, o.x);
+                    buf_store1<AUX>(ws, bin0 + 1 < (unsigned)NB ? off + 4 : kOOB, o.y);
+                    buf_store1<AUX>(ws, bin0 + 2 < (unsigned)NB ? off + 8 : kOOB, o.z);
+                    buf_store1<AUX>(ws, bin0 + 3 < (unsigned)NB ? off + 12 : kOOB, o.w);
+                }
             }
         }
     };

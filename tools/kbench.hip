@@ -338,21 +338,21 @@ int main(int argc, char** argv)
     }
     rroi_align_debug_set_prologue_aux(0);
     rroi_align_debug_set_prologue_blocks(3);
-    for (int aux : {16, 2}) {
-        for (int paux : {0, 16}) {
-            rroi_align_debug_set_store_aux(aux);
-            rroi_align_debug_set_prologue_aux(paux);
-            for (int wpc : {10, 12, 14}) {
-                rroi_align_debug_set_waves_per_cu(wpc);
-                const double pipe = T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 10, 2) / 20;
-                char nm[96];
-                snprintf(nm, 96, "pipeline step, store aux=%d prologue aux=%d waves/CU=%d", aux, paux, wpc);
-                report(nm, pipe, MB);
-            }
-        }
-    }
     rroi_align_debug_set_store_aux(2);
     rroi_align_debug_set_prologue_aux(0);
+    for (int wpc : {12, 13, 14}) {
+        rroi_align_debug_set_waves_per_cu(wpc);
+        char nm[96];
+        for (int dbg : {0, 1}) {
+            rroi_align_debug_set_fwd_dbg(dbg);
+            snprintf(nm, 96, "gather %d waves/CU ablation=%d", wpc, dbg);
+            report(nm, T.us([&] { stage(2); }, 100), MB);
+        }
+        rroi_align_debug_set_fwd_dbg(0);
+        const double pipe = T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 10, 2) / 20;
+        snprintf(nm, 96, "pipeline step waves/CU=%d", wpc);
+        report(nm, pipe, MB);
+    }
     rroi_align_debug_set_waves_per_cu(12);
     report("product all", T.us([&] { stage(3); }, 100), MB);
 
