@@ -234,3 +234,32 @@ def test_input_validation(ext):
     with pytest.raises(ValueError):
         ext.forward(F[0], R, 8, 8, 1.0)
     assert ext.forward(F, R[:0], 8, 8, 1.0).shape == (0, 4, 8, 8)
+
+
+def test_random_shape_sweep(ext, oracle):
+    """Seeded sweep over the parameter regimes of SURVEY.md 3.5 and beyond: channel counts that
+    are not multiples of 4 or 32, pooled sizes whose product is not a multiple of 4 or 64, maps
+    with odd sizes, several images, scales 1 / 0.5 / 0.25 -- every path, bit-exact."""
+    rng = np.random.default_rng(2024)
+    for trial in range(36):
+        C = int(rng.choice([1, 3, 4, 5, 31, 32, 33, 64, 70, 96]))
+        H, W = int(rng.integers(9, 90)), int(rng.integers(9, 120))
+        B = int(rng.integers(1, 4))
+        ph = int(rng.choice([1, 2, 8, 11, 13, 32]))
+        pw = int(rng.integers(1, 130))
+        s = float(rng.choice([1.0, 0.5, 0.25]))
+        R = int(rng.integers(1, 40))
+        f, r = Wk.bench_inputs(R=R, C=C, H=H, W=W, img=int(W / s), seed=1000 + trial, batch=B)
+        r[:, 2] = rng.uniform(0, H / s, R)  # cy in the image space of a non-square map
+        r[:, 3] = rng.uniform(2, 40, R) / (s * 4)
+        r[:, 4] = r[:, 3] * rng.uniform(0.3, 12, R)
+        want = oracle.forward_c(f, r, ph, pw, s, threads=8)
+        for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+            got = run_fwd(ext, f, r, ph, pw, s, p)
+            n, d = mismatch(got, want)
+            assert n == 0, f"trial {trial} C={C} {H}x{W} B={B} {ph}x{pw} s={s} R={R} path={p}: {n} differ (max {d})"
+        gout = np.random.default_rng(trial).standard_normal(want.shape).astype(np.float32)
+        gwant = oracle.backward_c(gout, r, f.shape, s)
+        for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+            g = ext.backward(dev(gout), dev(r), f.shape, s, path=p).cpu().numpy()
+            assert np.abs(g - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max())), f"trial {trial} bwd path={p}"
