@@ -55,12 +55,12 @@ def cpu_baseline(feats, rois):
     from oracle import rroi_align_oracle as O
     c = CFG
     cores = O.max_threads()
-    # bounded sample: the full 512-ROI workload once on 1 thread (a few s) and 3x on all cores
+    # bounded sample: 128 of the 512 ROIs on 1 thread (~1 s) and the full workload 6x on all cores
     t0 = time.perf_counter()
     O.forward_c(feats, rois[:128], c["PH"], c["PW"], c["scale"], threads=1)
     t1 = (time.perf_counter() - t0) * 4.0  # 128 of 512 ROIs
     best = float("inf")
-    for _ in range(3):
+    for _ in range(6):
         t0 = time.perf_counter()
         O.forward_c(feats, rois, c["PH"], c["PW"], c["scale"], threads=cores)
         best = min(best, time.perf_counter() - t0)
@@ -68,7 +68,7 @@ def cpu_baseline(feats, rois):
     return {
         "value": round(len(rois) / best, 1), "unit": "ROIs/s", "cores": cores, "kind": "port",
         "sample": "full workload (512 ROIs x 256 ch x 8x64), oracle/rroi_align_oracle.c hoisted "
-                  "forward, OpenMP over ROIs, best of 3; single-thread (128-ROI sample x4): "
+                  "forward, OpenMP over ROIs, best of 6; single-thread (128-ROI sample x4): "
                   "%.1f ROIs/s" % (len(rois) / t1),
         "ms_per_step": round(best * 1e3, 2),
     }, touched
