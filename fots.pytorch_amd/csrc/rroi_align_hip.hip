@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
     // instruction reads two 512-byte runs.  phase 2 mapping: lane -> (channel quad, pixel).
     const int x4 = lane & 31, csub = lane >> 5;
     const int cq = lane & 7, pl = lane >> 3;
-    const bool vec_ok = (HW & 3) == 0;  // rows of 16-byte aligned float4 (p0 is a multiple of 128)
+    // rows of 16-byte aligned float4 (p0 is a multiple of 128): needs HW % 4 == 0 and an aligned base
+    const bool vec_ok = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(nchw) & 15) == 0;
 
     v4f r[4];
     auto load_tile = [&](int tile) {

@@ -263,3 +263,20 @@ def test_random_shape_sweep(ext, oracle):
         for p in (ext.PATH_DIRECT, ext.PATH_TILED):
             g = ext.backward(dev(gout), dev(r), f.shape, s, path=p).cpu().numpy()
             assert np.abs(g - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max())), f"trial {trial} bwd path={p}"
+
+
+def test_views_with_storage_offsets(ext, oracle):
+    """Batch slices and odd-sized maps: the features pointer need not be 16-byte aligned and
+    H*W need not be a multiple of 4 (the prologue then reads scalars)."""
+    f, r = Wk.bench_inputs(R=12, C=41, H=33, W=45, img=180, seed=31, batch=3)
+    F = dev(f)
+    r1 = r.copy()
+    r1[:, 0] = np.minimum(r1[:, 0], 1)
+    want = oracle.forward_c(f[1:], r1, 8, 40, 0.25)
+    sub = F[1:]                      # contiguous view, storage offset 41*33*45 floats: not a multiple of 16 B
+    assert sub.is_contiguous() and sub.data_ptr() % 16 != 0
+    for p in (ext.PATH_TILED, ext.PATH_DIRECT):
+        assert eq(ext.forward(sub, dev(r1), 8, 40, 0.25, path=p).cpu().numpy(), want)
+    # a strided channel slice is made contiguous by the Python surface
+    want2 = oracle.forward_c(f[:, 8:24], r, 8, 40, 0.25)
+    assert eq(ext.forward(F[:, 8:24], dev(r), 8, 40, 0.25).cpu().numpy(), want2)
