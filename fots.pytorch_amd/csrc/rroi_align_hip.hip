@@ -1312,7 +1312,9 @@ int rroi_align_forward_stages_hip(const float* features, int feature_layout, flo
     return launch_status();
 }
 
-// exploration knobs (not part of the public ABI)
+// Exploration knobs used by tools/kbench.hip for the sweeps and ablations quoted in DESIGN.md.
+// They are NOT part of the ABI (not declared in include/rroi_align_hip.h); the defaults are the
+// shipped configuration.
 int rroi_align_debug_set_store_aux(int v)
 {
     const int old = g_store_aux;
