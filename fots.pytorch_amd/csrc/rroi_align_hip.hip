@@ -71,13 +71,15 @@ __device__ __forceinline__ void lds_wave_sync()
 __device__ __forceinline__ float as_f(unsigned u) { return __uint_as_float(u); }
 __device__ __forceinline__ unsigned as_u(float f) { return __float_as_uint(f); }
 
-// (int)x with the semantics of v_cvt_i32_f32 / cvt.rzi.s32.f32: saturating, NaN -> 0.
+// (int)x as the reference's device code performs it (cvt.rzi.s32.f32): truncating, saturating,
+// NaN -> 0.  That is exactly v_cvt_i32_f32; it is emitted directly because a C cast leaves the
+// out-of-range cases undefined, and the equivalent compare chain costs 12 instructions and three
+// branches per conversion in the gather kernel's geometry phase.
 __device__ __forceinline__ int f2i_sat(float x)
 {
-    if (x != x) return 0;
-    if (x >= 2147483648.0f) return INT32_MAX;
-    if (x <= -2147483648.0f) return INT32_MIN;
-    return (int)x;
+    int r;
+    asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 // kernel.cu:58-84.  Every * and + below is one separately rounded fp32
@@ -391,15 +393,15 @@ __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois,
 // ------------------------------------------------------------------------------------
 // K1: the hot kernel.  One wave per block; block -> channel chunk k = blockIdx %
 // nchunks (XCD affinity) and a grid-stride loop over (roi, 64-bin tile) items.
-//   phase A  lane = bin: geometry -> 32-byte tap record in LDS (4 byte offsets,
-//            flags, rx, ry).  With ZP an invalid tap (or any tap of a masked bin)
-//            points at the slice's zero pixel, so validity costs nothing later.
-//   phase B  lane = (bin b of 8, channel quad q of 8): first tap always, the
-//            other three only where the bin really has a second column / row,
-//            under the exec mask; taps that alias (dx == 0 / dy == 0) are
-//            resolved by register selects, which keeps the reference's four-term
-//            blend exact for non-finite features too; depth-2 software pipeline.
-//   phase C  the [32 ch][64 bin] tile leaves LDS as 16-byte stores, 256 B per row.
+//   phase A  lane = bin: geometry -> one 16-byte tap record per bin in LDS, sorted by
+//            class (bins with <= 2 distinct taps, bins with 4); an invalid tap is the
+//            out-of-range offset kOOB, which the buffer descriptor turns into 0.0.
+//   phase B  lane = (bin b of 8, channel quad q of 8): 2 or 4 buffer loads per group
+//            of 8 bins, blend, transpose through LDS; depth-2 software pipeline.
+//   phase C  the [32 ch][64 bin] tile leaves LDS as 16-byte streaming stores, 256 B
+//            per row.
+// The three phases of consecutive items are interleaved around the store burst, see the
+// loop at the end.
 // ------------------------------------------------------------------------------------
 template <bool VEC_STORE, int AUX>
 __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
@@ -417,8 +419,16 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     //   masked bins (pw > roi_pooled_width) are in no group -- phase C writes their zeros.
     // Typical tile: 5 LO + 2 HI groups = 18 load instructions instead of 32.
     constexpr int kMaxGroups = kIters + 2;  // two classes, each padded to a multiple of 8
-    __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride];
-    __shared__ __attribute__((aligned(16))) uint4 G[kMaxGroups * kBinsPerIter * 2];
+    constexpr unsigned kPadPos = kTileBins;  // "bin position" of a padding record
+    // T: rows 0..31 are the tile; the tail absorbs the writes of padding records (4 rows at the
+    // tile's pitch, 32 columns).  LDS is granted in 1280-byte granules on gfx950: the block must
+    // stay <= 12800 B for 12 waves per CU.
+    __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride + 3 * kTStride + 32];
+    // tap records of two items: item i+1 is sampled out of one set while the other is being
+    // built for item i+2
+    constexpr int kRecs = kMaxGroups * kBinsPerIter;
+    __shared__ __attribute__((aligned(16))) uint4 Gbuf[2 * kRecs];
+    __shared__ unsigned char HPbuf[2 * kRecs];
 
     const unsigned lane = threadIdx.x;
     const unsigned k = blockIdx.x % (unsigned)nchunks;
@@ -446,13 +456,15 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     unsigned g_lo = 0, g_hi = 0;          // groups of the current item (wave-uniform)
     unsigned long long act_mask = 0;      // bins of the current item that are in a group
 
-    // phase A of one item: lane = bin, geometry -> sorted 32-byte tap records in LDS:
-    //   LO: {off_lt, off_2nd, w_lt, w_2nd}      HI: {off_lt, off_rt, off_lb, off_rb}
-    //   both: {dx|dy flags | bin position << 8, rx, ry, -}
+    // phase A of one item: lane = bin, geometry -> sorted 16-byte tap records in LDS:
+    //   LO: {off_lt, off_2nd, w_lt, bin position}      (w_2nd = 1 - w_lt, see blend_lo)
+    //   HI: {off_lt, off_rt, off_lb, off_rb}, bin position in HP[]   (all four weights are 1/4)
     // Offsets are byte offsets into the slice; kOOB reads as 0.0, which is what
     // kernel.cu:116-126 substitutes for a tap outside the map.
-    auto geometry = [&](const Affine& A, unsigned t, unsigned& n_lo_groups, unsigned& n_hi_groups,
-                        unsigned long long& amask) {
+    auto geometry = [&](const Affine& A, unsigned t, unsigned p, unsigned& n_lo_groups,
+                        unsigned& n_hi_groups, unsigned long long& amask) {
+        uint4* const G = Gbuf + p * kRecs;
+        unsigned char* const HP = HPbuf + p * kRecs;
         const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
         const unsigned bin = t * kTileBins + lane;
         const unsigned ph = fdiv(bin, div_pw);
@@ -484,34 +496,28 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         const unsigned long long below = (1ull << lane) - 1ull;
         const unsigned idx = lo ? __popcll(m_lo & below) : hi_base + __popcll(m_hi & below);
         const float rx = bcx - fx, ry = bcy - fy;
-        float wlt, wrt, wrb, wlb;
-        tap_weights(rx, ry, wlt, wrt, wrb, wlb);
+        const float wlt = (1.0f - rx) * (1.0f - ry);  // kernel.cu:131
         if (active) {
-            if (hi)
-                G[2 * idx + 0] = make_uint4(o_lt, o_rt, o_lb, o_rb);
-            else  // the one other distinct tap and its weight: rt (dx) or lb (dy); none -> 0 * 0
-                G[2 * idx + 0] = make_uint4(o_lt, dx ? o_rt : o_lb, as_u(wlt), as_u(dx ? wrt : wlb));
-            G[2 * idx + 1] = make_uint4((dx ? kDx : 0u) | (dy ? kDy : 0u) | (lane << 8), as_u(rx), as_u(ry), 0u);
+            // LO: the one other distinct tap is rt (dx) or lb (dy); neither -> kOOB, weight 0
+            G[idx] = make_uint4(o_lt, dx ? o_rt : o_lb, hi ? o_lb : as_u(wlt), hi ? o_rb : lane);
+            HP[idx] = (unsigned char)lane;
         }
         // pad both classes to whole groups with records that load nothing and store nowhere
         const unsigned pad_lo = hi_base - n_lo, pad_hi = n_hi_groups * kBinsPerIter - n_hi;
         if (lane < pad_lo + pad_hi) {
-            const unsigned pidx = lane < pad_lo ? n_lo + lane : hi_base + n_hi + (lane - pad_lo);
-            G[2 * pidx + 0] = lane < pad_lo ? make_uint4(kOOB, kOOB, 0u, 0u) : make_uint4(kOOB, kOOB, kOOB, kOOB);
-            G[2 * pidx + 1] = make_uint4(64u << 8, 0u, 0u, 0u);
+            const bool plo = lane < pad_lo;
+            const unsigned pidx = plo ? n_lo + lane : hi_base + n_hi + (lane - pad_lo);
+            G[pidx] = make_uint4(kOOB, kOOB, plo ? 0u : kOOB, plo ? kPadPos : kOOB);
+            HP[pidx] = (unsigned char)kPadPos;
         }
     };
-    auto slice_rsrc = [&](const Affine& A) {
-        const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
-        const float* base = map + (size_t)(batch_ok ? A.batch : 0) * lay.img_stride + (size_t)k * lay.chunk_stride;
-        return make_rsrc(base, lay.slice_bytes);
-    };
-
-    uint4 ra[2], rb[2];
+    uint4 ra[2];
+    unsigned hpos[2];
     v4f lt[2], rt[2], lb[2], rbv[2];
-    auto fetch = [&](unsigned grp, int s) {
-        ra[s] = G[2 * (grp * kBinsPerIter + b) + 0];
-        rb[s] = G[2 * (grp * kBinsPerIter + b) + 1];
+    auto fetch_lo = [&](unsigned p, unsigned grp, int s) { ra[s] = Gbuf[p * kRecs + grp * kBinsPerIter + b]; };
+    auto fetch_hi = [&](unsigned p, unsigned grp, int s) {
+        ra[s] = Gbuf[p * kRecs + grp * kBinsPerIter + b];
+        hpos[s] = HPbuf[p * kRecs + grp * kBinsPerIter + b];
     };
     auto issue_lo = [&](__amdgpu_buffer_rsrc_t rs, int s) {
         // kOOB + q_bytes (or anything + kOOB) stays out of range: no wrap below 2^32
@@ -524,46 +530,42 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         lb[s] = buf_load(rs, ra[s].z + q_bytes);
         rbv[s] = buf_load(rs, ra[s].w + q_bytes);
     };
-    auto put = [&](int s, v4f v) {
-        const unsigned pos = rb[s].x >> 8;
-        if (pos < (unsigned)kTileBins) {  // padding records store nowhere
-            float* tw = T + (q * 4) * kTStride + (pos ^ wswz);
-            tw[0 * kTStride] = v.x;
-            tw[1 * kTStride] = v.y;
-            tw[2 * kTStride] = v.z;
-            tw[3 * kTStride] = v.w;
-        }
-    };
-    auto blend4 = [&](int s, v4f t_lt, v4f t_rt, v4f t_rb, v4f t_lb) {
-        float wlt, wrt, wrb, wlb;
-        tap_weights(as_f(rb[s].y), as_f(rb[s].z), wlt, wrt, wrb, wlb);
-        v4f v = z4;  // kernel.cu:136-141, four channels at a time
-        v += t_lt * wlt;
-        v += t_rt * wrt;
-        v += t_rb * wrb;
-        v += t_lb * wlb;
-        return v;
+    float* const t_row = T + (q * 4) * kTStride;
+    float* const t_pad = T + kChunk * kTStride + (lane & 31u);
+    auto put = [&](unsigned pos, v4f v) {
+        float* tw = pos < (unsigned)kTileBins ? t_row + (pos ^ wswz) : t_pad;
+        tw[0 * kTStride] = v.x;
+        tw[1 * kTStride] = v.y;
+        tw[2 * kTStride] = v.z;
+        tw[3 * kTStride] = v.w;
     };
     auto blend_lo = [&](int s) {
-        // At most two distinct pixels.  The reference still adds all four terms
-        // (kernel.cu:138-141); the two that re-read a pixel carry weight exactly 0 (rx or ry
-        // is 0), so for finite taps they add +-0 and  (0 + lt*w_lt) + t2*w_2nd  is the same
-        // value bit for bit.  Both distinct taps have non-zero weights, so a non-finite tap
-        // makes this result non-finite -- only then (0 * inf = NaN in the reference) the
-        // four-term form is evaluated.
-        const v4f t_lt = lt[s], t_2 = rt[s];
+        // At most two distinct pixels p (= lt) and p2, with weights w and 1 - w
+        // (w = 1: p alone; w = 1/2: p and its right OR lower neighbour; kernel.cu:131-134 with
+        // rx, ry in {0, 1/2}).  The reference adds all four terms (:138-141); the two that
+        // re-read p or p2 carry weight exactly 0.  So
+        //   taps finite      -> those terms add +-0 and the sum is  (0 + p*w) + p2*(1-w);
+        //   a tap non-finite -> the reference's 0 * tap is NaN, and so is its sum.
+        // The two-term sum is finite exactly when both taps are (both weights are non-zero and
+        // at most 1), so adding  v - v  (0, or NaN when v is not finite) reproduces the
+        // reference bit for bit in both cases.  A NaN weight (centre at infinity) gives NaN
+        // either way.
+        const float w = as_f(ra[s].z), w2 = 1.0f - w;
         v4f v = z4;
-        v += t_lt * as_f(ra[s].z);
-        v += t_2 * as_f(ra[s].w);
-        const v4f d = v - v;  // 0 for finite lanes, NaN otherwise
-        if (__builtin_expect(__any((d.x + d.y) + (d.z + d.w) != 0.0f), 0)) {
-            const unsigned f = rb[s].x;
-            const bool dx = f & kDx, dy = f & kDy;
-            v = blend4(s, t_lt, dx ? t_2 : t_lt, (dx || dy) ? t_2 : t_lt, dy ? t_2 : t_lt);
-        }
-        put(s, v);
+        v += lt[s] * w;
+        v += rt[s] * w2;
+        v += v - v;
+        put(ra[s].w, v);
     };
-    auto blend_hi = [&](int s) { put(s, blend4(s, lt[s], rt[s], rbv[s], lb[s])); };
+    auto blend_hi = [&](int s) {
+        // four distinct pixels: dx and dy, so rx = ry = 1/2 and every weight is 1/4
+        v4f v = z4;  // kernel.cu:136-141, four channels at a time
+        v += lt[s] * 0.25f;
+        v += rt[s] * 0.25f;
+        v += rbv[s] * 0.25f;
+        v += lb[s] * 0.25f;
+        put(hpos[s], v);
+    };
     // An empty asm that "rewrites" the current group's taps: placed right after the next
     // group's loads are issued, it pins the first use of the current taps (and with it the
     // s_waitcnt) BEHIND that issue.  Without it the compiler hoists the first multiplies of the
@@ -607,23 +609,49 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         }
     };
 
-    unsigned item = slot;
-    if (item >= items) return;
-    unsigned n = fdiv(item, div_tiles);
-    unsigned t = item - n * (unsigned)ntiles;
-    Affine A = aff[n];
-    geometry(A, t, g_lo, g_hi, act_mask);
+    // Software pipeline over the items of this wave.  gfx950 counts loads and stores with ONE
+    // in-order counter, so a load issued after a tile's stores cannot be consumed before those
+    // stores are acknowledged by the memory system (microseconds, with 256 MiB streaming out).
+    // Per iteration, with the tile of item i-1 complete in T and the records of item i in set p:
+    //   1. the first loads of item i are issued (they are AHEAD of the stores in the counter);
+    //   2. tile i-1 leaves: LDS -> registers -> 8 x 1 KiB streaming stores;
+    //   3. geometry of item i+1 -> record set p^1: ~250 instructions that depend on no memory
+    //      access, run while the stores drain;
+    //   4. phase B of item i -> T (its later groups do wait for the store acknowledgements).
+    unsigned cur = slot;
+    if (cur >= items) return;
+    unsigned n = fdiv(cur, div_tiles);
+    unsigned t = cur - n * (unsigned)ntiles;
+    unsigned p = 0;
+    unsigned n_prev = 0, t_prev = 0;
+    unsigned long long mask_prev = 0;
+    bool have_prev = false;
+    unsigned g_lo_next = 0, g_hi_next = 0;
+    unsigned long long mask_next = 0;
+    {
+        const Affine A = aff[n];
+        geometry(A, t, 0, g_lo, g_hi, act_mask);
+    }
+    int batch = aff[n].batch;
     lds_wave_sync();
-    __amdgpu_buffer_rsrc_t rs = slice_rsrc(A);
-    fetch(0, 0);
-    issue_lo(rs, 0);  // LO group 0 of the first item
 
     for (;;) {
-        const unsigned item_next = item + nslots;
-        const bool has_next = item_next < items;
-        const unsigned n_next = has_next ? fdiv(item_next, div_tiles) : n;
-        const unsigned t_next = item_next - n_next * (unsigned)ntiles;
-        const Affine A_next = aff[n_next];  // in flight during phase B
+        const unsigned nxt = cur + nslots;
+        const bool has_next = nxt < items;
+        const unsigned n_next = has_next ? fdiv(nxt, div_tiles) : n;
+        const unsigned t_next = nxt - n_next * (unsigned)ntiles;
+        const Affine A_next = aff[n_next];  // scalar loads, in flight during steps 1-2
+
+        const bool batch_ok = batch >= 0 && batch < batch_size;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(
+            map + (size_t)(batch_ok ? batch : 0) * lay.img_stride + (size_t)k * lay.chunk_stride, lay.slice_bytes);
+        fetch_lo(p, 0, 0);
+        issue_lo(rs, 0);  // LO group 0 (there always is one)
+        if (have_prev) {
+            store_tile(n_prev, t_prev, mask_prev);
+            lds_wave_sync();  // T has been read: free for this item's blends
+        }
+        if (has_next) geometry(A_next, t_next, p ^ 1u, g_lo_next, g_hi_next, mask_next);
 
         // ---- phase B: LO groups (group 0 is already in flight), then HI groups; the loads of
         // group g+1 are issued before group g is blended.  The loops are unrolled with an early
@@ -634,7 +662,7 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         for (int it = 0; it < kIters; ++it) {
             const int s = it & 1;
             if ((unsigned)(it + 1) < g_lo) {
-                fetch(it + 1, s ^ 1);
+                fetch_lo(p, it + 1, s ^ 1);
                 issue_lo(rs, s ^ 1);
                 pin_lo(s);
                 blend_lo(s);
@@ -646,13 +674,13 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
             }
         }
         if (g_hi > 0) {
-            fetch(g_lo, 0);
+            fetch_hi(p, g_lo, 0);
             issue_hi(rs, 0);
 #pragma unroll
             for (int it = 0; it < kIters; ++it) {
                 const int s = it & 1;
                 if ((unsigned)(it + 1) < g_hi) {
-                    fetch(g_lo + it + 1, s ^ 1);
+                    fetch_hi(p, g_lo + it + 1, s ^ 1);
                     issue_hi(rs, s ^ 1);
                     pin_hi(s);
                     blend_hi(s);
@@ -664,26 +692,23 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
                 }
             }
         }
-        const unsigned long long cur_mask = act_mask;
-        lds_wave_sync();  // T complete; every record of this item has been fetched: G is free
+        lds_wave_sync();  // T complete; record set p^1 complete
         if (!has_next) {
-            store_tile(n, t, cur_mask);
+            store_tile(n, t, act_mask);
             break;
         }
-        // The next item's records are built and its first loads issued BEFORE this item's
-        // stores: gfx950 has one in-order counter for loads and stores, so a load issued after
-        // the stores could not be consumed before they are acknowledged by the memory system.
-        geometry(A_next, t_next, g_lo, g_hi, act_mask);
-        lds_wave_sync();
-        rs = slice_rsrc(A_next);
-        fetch(0, 0);
-        issue_lo(rs, 0);
-        store_tile(n, t, cur_mask);
-        lds_wave_sync();
-        item = item_next;
+        n_prev = n;
+        t_prev = t;
+        mask_prev = act_mask;
+        have_prev = true;
+        cur = nxt;
         n = n_next;
         t = t_next;
-        A = A_next;
+        batch = A_next.batch;
+        g_lo = g_lo_next;
+        g_hi = g_hi_next;
+        act_mask = mask_next;
+        p ^= 1u;
     }
 }
 
@@ -1097,10 +1122,10 @@ bool shape_ok(int batch_size, int num_rois, int height, int width, int channels,
     return true;
 }
 
-// grid for the tiled kernels: one wave per block, 12 waves per CU (measured optimum: LDS
-// admits 15, but beyond 12 the L1 hit rate of the tap loads drops faster than the extra
-// latency hiding pays), a multiple of lcm(nchunks, 8) so that blockIdx % nchunks is also
-// stable per XCD.
+// grid for the tiled kernels: one wave per block, 12 waves per CU -- what the forward
+// kernel's 12.4 KB of LDS admits (LDS is granted in 1280-byte granules; a grid larger than
+// the resident set would run its surplus blocks as a second, mostly empty round) -- and a
+// multiple of lcm(nchunks, 8) so that blockIdx % nchunks is also stable per XCD.
 int g_waves_per_cu = 12;
 
 int tiled_grid(long items, int nchunks)

@@ -86,6 +86,27 @@ def test_forward_nonfinite_features(ext, oracle):
         assert mismatch(run_fwd(ext, f, r, 8, 64, 0.25, p), want)[0] == 0
 
 
+def test_forward_nonfinite_scattered(ext, oracle):
+    """+-inf, NaN and near-overflow values sprinkled over the whole map (3 % of the pixels), so that
+    every blend class meets them: single-tap bins (weight 1), two-tap bins (1/2, 1/2) and four-tap
+    bins (1/4 each), with the non-finite value on the weighted tap, on the zero-weight alias, or
+    both.  The tiled kernel's two-term fast path must still equal the reference's four-term sum."""
+    rng = np.random.default_rng(21)
+    f, r = Wk.bench_inputs(R=96, C=40, seed=21)
+    H, W = f.shape[2:]
+    sel = rng.random((H, W))
+    f[0, :, sel < 0.010] = np.inf
+    f[0, :, (sel >= 0.010) & (sel < 0.018)] = -np.inf
+    f[0, :, (sel >= 0.018) & (sel < 0.024)] = np.nan
+    f[0, :, (sel >= 0.024) & (sel < 0.030)] = 3.0e38
+    f[0, ::2, (sel >= 0.024) & (sel < 0.030)] = -3.0e38
+    want = oracle.forward_c(f, r, 8, 64, 0.25)
+    assert np.isnan(want).any() and np.isinf(want).any()
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+        n, d = mismatch(run_fwd(ext, f, r, 8, 64, 0.25, p), want)
+        assert n == 0, f"path {p}: {n} elements differ"
+
+
 @pytest.mark.parametrize("name", ["oracle_cfg1", "oracle_mid", "oracle_edge"])
 def test_golden_fixtures(ext, name):
     z = np.load(os.path.join(GOLD, name + ".npz"))

@@ -256,6 +256,30 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    if (argc > 1 && std::string(argv[1]) == "abl") {
+        // gather-kernel ablations only: dbg bit 0 = no output stores, bit 1 = all taps out of range
+        auto stage = [&](int s) {
+            int rc = rroi_align_forward_stages_hip(feat, 0, 0.25f, 1, R, H, W, C, PH, PW, rois_d, out, ws, wsb, 2, s, 0);
+            if (rc != 1) { fprintf(stderr, "stage rc=%d\n", rc); exit(1); }
+        };
+        for (int i = 0; i < 300; ++i) stage(3);  // clocks
+        CK(hipDeviceSynchronize());
+        for (int wpc : {8, 12}) {
+            rroi_align_debug_set_waves_per_cu(wpc);
+            for (int dbg : {0, 1, 2, 3}) {
+                rroi_align_debug_set_fwd_dbg(dbg);
+                char nm[96];
+                snprintf(nm, 96, "gather %d waves/CU ablation=%d", wpc, dbg);
+                report(nm, T.us([&] { stage(2); }, 100), MB);
+            }
+            rroi_align_debug_set_fwd_dbg(0);
+            const double pipe = T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 10, 2) / 20;
+            char nm[96];
+            snprintf(nm, 96, "pipeline step waves/CU=%d", wpc);
+            report(nm, pipe, MB);
+        }
+        return 0;
+    }
     report("hipMemsetAsync 256MiB", T.us([&] { CK(hipMemsetAsync(out, 0, out_elems * 4, 0)); }), MB);
     for (int g : {2048, 4096, 8192, 16384})
     {
