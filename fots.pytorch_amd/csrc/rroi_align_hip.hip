@@ -574,8 +574,13 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     auto pin_hi = [&](int s) { asm volatile("" : "+v"(lt[s]), "+v"(rt[s]), "+v"(lb[s]), "+v"(rbv[s])); };
 
     // phase C of one item: [rows < C] x [64 bins] -> 256-byte row segments
-    auto store_tile = [&](unsigned n, unsigned t, unsigned long long cur_mask) {
-        if (dbg & 1) return;  // (ablation knob: dbg & 1 skips the output stores)
+    // `live` = false turns every store into an out-of-range one (dropped by the descriptor
+    // check) instead of branching around them: the instruction stream of the loop must be the
+    // same on every path, or the compiler's s_waitcnt counts -- which take the most
+    // conservative value where paths merge -- degrade to vmcnt(0) and every blend waits for
+    // the store acknowledgements.  (Also the ablation knob: dbg & 1 drops the output stores.)
+    auto store_tile = [&](unsigned n, unsigned t, unsigned long long cur_mask, bool live) {
+        live = live && !(dbg & 1);
         // descriptor over this (roi, chunk) block of the output: rows >= C fall out of range
         float* obase = out + ((size_t)n * C + k * kChunk) * NB;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, chans_here * (unsigned)NB * 4u);
@@ -598,12 +603,12 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
                 const unsigned off = (r * (unsigned)NB + bin0) * 4u;
                 const v4f o = {a0 ? v[s4].x : 0.f, a1 ? v[s4].y : 0.f, a2 ? v[s4].z : 0.f, a3 ? v[s4].w : 0.f};
                 if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
-                    buf_store<AUX>(ws, bin0 < (unsigned)NB ? off : kOOB, o);
+                    buf_store<AUX>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);
                 } else {
-                    buf_store1<AUX>(ws, bin0 + 0 < (unsigned)NB ? off + 0 : kOOB, o.x);
-                    buf_store1<AUX>(ws, bin0 + 1 < (unsigned)NB ? off + 4 : kOOB, o.y);
-                    buf_store1<AUX>(ws, bin0 + 2 < (unsigned)NB ? off + 8 : kOOB, o.z);
-                    buf_store1<AUX>(ws, bin0 + 3 < (unsigned)NB ? off + 12 : kOOB, o.w);
+                    buf_store1<AUX>(ws, (live && bin0 + 0 < (unsigned)NB) ? off + 0 : kOOB, o.x);
+                    buf_store1<AUX>(ws, (live && bin0 + 1 < (unsigned)NB) ? off + 4 : kOOB, o.y);
+                    buf_store1<AUX>(ws, (live && bin0 + 2 < (unsigned)NB) ? off + 8 : kOOB, o.z);
+                    buf_store1<AUX>(ws, (live && bin0 + 3 < (unsigned)NB) ? off + 12 : kOOB, o.w);
                 }
             }
         }
@@ -647,10 +652,8 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
             map + (size_t)(batch_ok ? batch : 0) * lay.img_stride + (size_t)k * lay.chunk_stride, lay.slice_bytes);
         fetch_lo(p, 0, 0);
         issue_lo(rs, 0);  // LO group 0 (there always is one)
-        if (have_prev) {
-            store_tile(n_prev, t_prev, mask_prev);
-            lds_wave_sync();  // T has been read: free for this item's blends
-        }
+        store_tile(n_prev, t_prev, mask_prev, have_prev);
+        lds_wave_sync();  // T has been read: free for this item's blends
         if (has_next) geometry(A_next, t_next, p ^ 1u, g_lo_next, g_hi_next, mask_next);
 
         // ---- phase B: LO groups (group 0 is already in flight), then HI groups; the loads of
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         }
         lds_wave_sync();  // T complete; record set p^1 complete
         if (!has_next) {
-            store_tile(n, t, act_mask);
+            store_tile(n, t, act_mask, true);
             break;
         }
         n_prev = n;
@@ -766,8 +769,182 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// Backward, tiled: scatter into a zeroed chunk-major gradient (B, C/32, H*Wp, 32) with
-// hardware fp32 atomics, then relayout to NCHW.  Same item decomposition as the forward.
+// K3g: backward as a GATHER (the default tiled backward).  The scatter of K3 is bound by the
+// fp32 atomic rate (113 M lane-atomics at cfg3 -> 0.65 ms).  The (bin, tap) -> pixel relation
+// does not depend on the channel, so it is inverted ONCE per call:
+//   pairs   count pass + exclusive scan + fill pass: for every map pixel the list of
+//           (bin, weight) that the reference's four atomicAdds (kernel.cu:267-274) send to it
+//           -- 442 K pairs of 8 bytes at cfg3, integer atomics on 25.6 K counters;
+//   relayout top_diff (R, C, PH*PW) -> chunk-major (R, C/32, PH*PW + 1, 32) with the forward's
+//           prologue kernel, so that the 32 channels of one bin are one 128-byte line;
+//   gather  one (sub-)wave per pixel walks its list: a 16-byte load per lane and pair, all
+//           channels of the pixel accumulated in registers, one store.  No float atomics, no
+//           memset of the gradient.
+// Taps of a bin that alias one pixel (dx == 0 / dy == 0) become ONE pair: the reference adds
+// w*g and 0*g separately, which for finite g is w*g and for non-finite g is NaN either way;
+// the pair carries an "add 0*g as well" flag (sign bit of the weight) so that both cases are
+// reproduced.
+// ------------------------------------------------------------------------------------
+struct PairGeom {
+    unsigned px[4];   // compact pixel index b*H*W + y*W + x
+    float w[4];       // weight; sign bit set = the reference also adds 0*g to this pixel
+    int n;            // number of pairs of this bin (0..4)
+};
+
+__device__ __forceinline__ PairGeom bin_pairs(const Affine& A, unsigned ph, unsigned pw, bool in_range,
+                                              int height, int width, int batch_size)
+{
+    PairGeom g;
+    g.n = 0;
+    float bcx, bcy;
+    bool active = bin_centre(A, (int)ph, (int)pw, height, width, bcx, bcy);
+    active = active && in_range && A.batch >= 0 && A.batch < batch_size;
+    const Taps tp = make_taps(bcx, bcy, active, height, width, 1u);
+    const unsigned f = tp.flags;
+    if (!(f & kActive)) return g;
+    float wlt, wrt, wrb, wlb;
+    tap_weights(tp.rx, tp.ry, wlt, wrt, wrb, wlb);
+    const bool dx = f & kDx, dy = f & kDy;
+    const unsigned base = (unsigned)A.batch * (unsigned)(height * width) + tp.o_lt;  // o_lt = y0*W + x0
+    const float alias = (dx && dy) ? 1.0f : -1.0f;  // not all four taps distinct: some pixel also gets 0*g
+    auto emit = [&](unsigned px, float w) {
+        g.px[g.n] = px;
+        g.w[g.n] = w * alias;  // weights are positive (or NaN, but then every bound has failed)
+        ++g.n;
+    };
+    // kernel.cu:267-274; an aliased tap has the bounds of the tap it aliases
+    if (f & kB00) emit(base, wlt);
+    if (dx && (f & kB01)) emit(base + 1u, wrt);
+    if (dy && (f & kB10)) emit(base + (unsigned)width, wlb);
+    if (dx && dy && (f & kB11)) emit(base + (unsigned)width + 1u, wrb);
+    return g;
+}
+
+// FILL == false: cnt[pixel] += 1 per pair.  FILL == true: cnt counts back down, handing out the
+// slots of the pixel's segment [off[pixel], off[pixel+1]).
+template <bool FILL>
+__global__ __launch_bounds__(256) void rroi_bwd_pairs_kernel(
+    const Affine* __restrict__ aff, int num_rois, int height, int width, int pooled_width, int NB,
+    int batch_size, unsigned lines_per_roi, FastDiv div_nb, FastDiv div_pw, int* __restrict__ cnt,
+    const unsigned* __restrict__ off, uint2* __restrict__ pairs)
+{
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    const unsigned n = fdiv(idx, div_nb);
+    if (n >= (unsigned)num_rois) return;
+    const unsigned j = idx - n * (unsigned)NB;
+    const unsigned ph = fdiv(j, div_pw);
+    const unsigned pw = j - ph * (unsigned)pooled_width;
+    const Affine A = aff[n];
+    const PairGeom g = bin_pairs(A, ph, pw, true, height, width, batch_size);
+    for (int i = 0; i < g.n; ++i) {
+        if (!FILL) {
+            atomicAdd(cnt + g.px[i], 1);
+        } else {
+            const int slot = atomicAdd(cnt + g.px[i], -1) - 1;
+            // line index of (roi n, bin j) in chunk 0 of the relaid-out top_diff
+            pairs[off[g.px[i]] + (unsigned)slot] = make_uint2(n * lines_per_roi + j, as_u(g.w[i]));
+        }
+    }
+}
+
+// exclusive scan of cnt[0..P) -> off[0..P], one block; P is the number of map pixels
+__global__ __launch_bounds__(1024) void rroi_scan_kernel(const int* __restrict__ cnt, unsigned* __restrict__ off, unsigned P)
+{
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned carry_s;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (unsigned base = 0; base < P; base += 4096u) {
+        const unsigned i0 = base + tid * 4u;
+        unsigned v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = i0 + e < P ? (unsigned)cnt[i0 + e] : 0u;
+        const unsigned mine = v[0] + v[1] + v[2] + v[3];
+        unsigned incl = mine;  // inclusive scan over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d, 64);
+            if (lane >= (unsigned)d) incl += o;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        unsigned wbase = 0;
+        for (unsigned k = 0; k < wv; ++k) wbase += wsum[k];
+        unsigned run = carry_s + wbase + incl - mine;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (i0 + e < P) off[i0 + e] = run;
+            run += v[e];
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = run;
+        __syncthreads();
+    }
+    if (tid == 0) off[P] = carry_s;
+}
+
+// gather: `sub` = 8 * nchunks_pass lanes serve one pixel (lane -> chunk, channel quad); 64 / sub
+// pixels per wave.  The 16-byte loads of eight pairs are in flight together.
+__global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
+    const float* __restrict__ tdT, const unsigned* __restrict__ off, const uint2* __restrict__ pairs,
+    float* __restrict__ gcm, int C, int height, int width, int pitch, int batch_size, int nchunks,
+    unsigned lines_per_chunk, unsigned sub_shift, FastDiv div_hw, FastDiv div_w)
+{
+    const unsigned tid = blockIdx.x * 256u + threadIdx.x;
+    const unsigned sub = 1u << sub_shift;              // lanes per pixel (8..64)
+    const unsigned sl = tid & (sub - 1u);              // lane within the pixel's group
+    const unsigned grp = tid >> sub_shift;             // pixel group id
+    const unsigned ngrp = (gridDim.x * 256u) >> sub_shift;
+    const unsigned HW = (unsigned)height * (unsigned)width;
+    const unsigned P = (unsigned)batch_size * HW;
+    const unsigned quad = sl & 7u;
+    const unsigned slice_px = (unsigned)height * (unsigned)pitch;
+    const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int kDepth = 8;
+
+    for (unsigned p = grp; p < P; p += ngrp) {
+        const unsigned beg = off[p], end = off[p + 1];
+        const unsigned b = fdiv(p, div_hw);
+        const unsigned yx = p - b * HW;
+        const unsigned y = fdiv(yx, div_w);
+        const unsigned x = yx - y * (unsigned)width;
+        // channel passes of `sub / 8` chunks each (one pass when C <= 256)
+        for (unsigned k0 = 0; k0 < (unsigned)nchunks; k0 += sub >> 3) {
+            const unsigned k = k0 + (sl >> 3);
+            const bool c_ok = k < (unsigned)nchunks && k * kChunk + quad * 4u < (unsigned)C;
+            const float* src = tdT + ((size_t)k * lines_per_chunk) * kChunk + quad * 4u;
+            v4f acc = z4;
+            for (unsigned i = beg; i < end; i += kDepth) {
+                uint2 e[kDepth];
+                v4f g[kDepth];
+#pragma unroll
+                for (int d = 0; d < kDepth; ++d) e[d] = i + d < end ? pairs[i + d] : make_uint2(0u, 0u);
+#pragma unroll
+                for (int d = 0; d < kDepth; ++d)
+                    g[d] = (c_ok && i + d < end) ? *reinterpret_cast<const v4f*>(src + (size_t)e[d].x * kChunk) : z4;
+#pragma unroll
+                for (int d = 0; d < kDepth; ++d) {
+                    if (i + d < end) {
+                        // kernel.cu:260-263: v_k = w_k * top_diff, then one add per tap
+                        acc += g[d] * as_f(e[d].y & 0x7fffffffu);
+                        if (e[d].y & 0x80000000u) acc += g[d] * 0.0f;
+                    }
+                }
+            }
+            if (c_ok) {
+                float* dst = gcm + (((size_t)b * nchunks + k) * slice_px + (size_t)y * pitch + x) * kChunk + quad * 4u;
+                *reinterpret_cast<v4f*>(dst) = acc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K3: backward as a SCATTER (RROI_PATH_TILED_ATOMIC; the first tiled backward, kept for
+// comparison and for problems whose pair lists do not fit 32-bit indices): into a zeroed
+// chunk-major gradient (B, C/32, H*Wp, 32) with hardware fp32 atomics, then relayout to NCHW.
+// Same item decomposition as the forward.
 // Measured on MI355X (tools/kbench): an atomic wave instruction that covers 2 full 128-byte
 // lines sustains 325 G lane-atomics/s, one that touches 8 lines at a 16-byte stride only
 // 80 G/s.  So the (bin, tap) contributions of a tile are first COMPACTED into a list (only
@@ -1187,6 +1364,51 @@ Workspace carve(void* ws, int batch_size, int channels, int height, int width, i
     return w;
 }
 
+// backward: [affine | chunk-major gradient | pixel counters | pixel offsets | pairs |
+//            chunk-major top_diff (R, nchunks, NB + 1, 32)]
+struct BwdWorkspace {
+    Affine* aff;
+    float* gcm;
+    int* cnt;
+    unsigned* off;
+    uint2* pairs;
+    float* tdT;
+    size_t gcm_bytes, cnt_bytes;
+    size_t bytes;
+    bool gather_ok;  // the gather formulation's 32-bit indices hold for this problem
+};
+
+BwdWorkspace carve_bwd(void* ws, int batch_size, int channels, int height, int width, int num_rois, int NB)
+{
+    BwdWorkspace w;
+    const size_t nchunks = (channels + kChunk - 1) / kChunk;
+    const size_t P = (size_t)batch_size * height * width;
+    const size_t R = num_rois > 0 ? num_rois : 1;
+    const size_t aff_bytes = align_up(R * sizeof(Affine), 256);
+    w.gcm_bytes = align_up((size_t)batch_size * nchunks * height * row_pitch(width) * kLineBytes, 256);
+    w.cnt_bytes = align_up(P * sizeof(int), 256);
+    const size_t off_bytes = align_up((P + 1) * sizeof(unsigned), 256);
+    const size_t pair_bytes = align_up(4 * R * NB * sizeof(uint2), 256);
+    const size_t td_bytes = align_up(R * nchunks * ((size_t)NB + 1) * kLineBytes, 256);
+    // pair slots and top_diff line indices are 32-bit
+    w.gather_ok = 4 * R * NB < (1ull << 32) && R * nchunks * ((size_t)NB + 1) < (1ull << 32) && P < (1ull << 31);
+    char* b = reinterpret_cast<char*>(ws);
+    w.aff = reinterpret_cast<Affine*>(b);
+    b += aff_bytes;
+    w.gcm = reinterpret_cast<float*>(b);
+    b += w.gcm_bytes;
+    w.cnt = reinterpret_cast<int*>(b);
+    b += w.cnt_bytes;
+    w.off = reinterpret_cast<unsigned*>(b);
+    b += off_bytes;
+    w.pairs = reinterpret_cast<uint2*>(b);
+    b += pair_bytes;
+    w.tdT = reinterpret_cast<float*>(b);
+    b += td_bytes;
+    w.bytes = aff_bytes + w.gcm_bytes + (w.gather_ok ? w.cnt_bytes + off_bytes + pair_bytes + td_bytes : 0);
+    return w;
+}
+
 // AUTO: the tiled path pays one pass over the whole map (read + write B*C*H*W);
 // the direct path pays ~4 uncoalesced taps per output.  Tiled wins once the
 // output is a few times larger than the map.
@@ -1217,10 +1439,13 @@ size_t rroi_align_forward_workspace_bytes(int batch_size, int channels, int heig
 }
 
 size_t rroi_align_backward_workspace_bytes(int batch_size, int channels, int height, int width,
-                                           int num_rois)
+                                           int num_rois, int pooled_height, int pooled_width)
 {
-    if (batch_size <= 0 || channels <= 0 || height <= 0 || width <= 0 || num_rois < 0) return 0;
-    return carve(nullptr, batch_size, channels, height, width, num_rois, RROI_LAYOUT_NCHW).bytes;
+    if (batch_size <= 0 || channels <= 0 || height <= 0 || width <= 0 || num_rois < 0 ||
+        pooled_height <= 0 || pooled_width <= 0)
+        return 0;
+    return carve_bwd(nullptr, batch_size, channels, height, width, num_rois,
+                     pooled_height * pooled_width).bytes;
 }
 
 int rroi_align_forward_hip(const float* features, int feature_layout, float spatial_scale,
@@ -1386,7 +1611,9 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!shape_ok(batch_size, num_rois, height, width, channels, pooled_height, pooled_width))
         return 0;
-    if (path != RROI_PATH_AUTO && path != RROI_PATH_DIRECT && path != RROI_PATH_TILED) return 0;
+    if (path != RROI_PATH_AUTO && path != RROI_PATH_DIRECT && path != RROI_PATH_TILED &&
+        path != RROI_PATH_TILED_ATOMIC)
+        return 0;
     if (!bottom_diff) return 0;
     const int NB = pooled_height * pooled_width;
     const size_t HW = (size_t)height * width;
@@ -1396,7 +1623,7 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
 
     const bool tiled = path == RROI_PATH_AUTO
                            ? pick_tiled(batch_size, channels, height, width, num_rois, NB)
-                           : path == RROI_PATH_TILED;
+                           : path != RROI_PATH_DIRECT;
     if (!tiled) {
         hipError_t e = hipMemsetAsync(bottom_diff, 0, in_bytes, stream);
         if (e != hipSuccess) return status_of(e);
@@ -1409,33 +1636,86 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
         return launch_status();
     }
 
-    const Workspace ws = carve(workspace, batch_size, channels, height, width, num_rois, RROI_LAYOUT_NCHW);
+    const BwdWorkspace ws = carve_bwd(workspace, batch_size, channels, height, width, num_rois, NB);
     if (!workspace || workspace_bytes < ws.bytes) return 0;
     const int nchunks = ceil_div(channels, kChunk);
     const int pitch = row_pitch(width);
-    hipError_t e = hipMemsetAsync(ws.cm, 0, (size_t)batch_size * nchunks * height * pitch * kLineBytes, stream);
-    if (e != hipSuccess) return status_of(e);
+    const int ptiles = ceil_div((long)HW, kRelayoutPx);
     hipLaunchKernelGGL(rroi_affine_kernel, dim3(ceil_div(num_rois, 256)), dim3(256), 0, stream,
                        rois, num_rois, pooled_height, spatial_scale, ws.aff);
     int st = launch_status();
     if (st != 1) return st;
-    const int ntiles = ceil_div(NB, kTileBins);
-    if ((long)num_rois * ntiles >= (1L << 31)) return 0;
-    const int grid = tiled_grid((long)num_rois * ntiles, nchunks);
-    const FastDiv dt = make_fastdiv((unsigned)ntiles), dp = make_fastdiv((unsigned)pooled_width);
-    if (NB % 4 == 0)
-        hipLaunchKernelGGL(rroi_bwd_tiled_kernel<true>, dim3(grid), dim3(kWave), 0, stream,
-                           top_diff, ws.aff, ws.cm, num_rois, channels, height, width, pitch,
-                           pooled_width, NB, batch_size, nchunks, ntiles, dt, dp);
-    else
-        hipLaunchKernelGGL(rroi_bwd_tiled_kernel<false>, dim3(grid), dim3(kWave), 0, stream,
-                           top_diff, ws.aff, ws.cm, num_rois, channels, height, width, pitch,
-                           pooled_width, NB, batch_size, nchunks, ntiles, dt, dp);
-    st = launch_status();
-    if (st != 1) return st;
-    const int ptiles = ceil_div((long)HW, kRelayoutPx);
+
+    if (path != RROI_PATH_TILED_ATOMIC && ws.gather_ok) {
+        // (1) pixel -> (bin, weight) lists: count, scan, fill
+        const unsigned P = (unsigned)((size_t)batch_size * HW);
+        hipError_t e = hipMemsetAsync(ws.cnt, 0, (size_t)P * sizeof(int), stream);
+        if (e != hipSuccess) return status_of(e);
+        const unsigned lines_per_chunk = (unsigned)NB + 1u;
+        const unsigned lines_per_roi = lines_per_chunk * (unsigned)nchunks;
+        const int pblocks = ceil_div((long)num_rois * NB, 256);
+        const FastDiv dnb = make_fastdiv((unsigned)NB), dpw = make_fastdiv((unsigned)pooled_width);
+        hipLaunchKernelGGL(rroi_bwd_pairs_kernel<false>, dim3(pblocks), dim3(256), 0, stream, ws.aff,
+                           num_rois, height, width, pooled_width, NB, batch_size, lines_per_roi, dnb,
+                           dpw, ws.cnt, ws.off, ws.pairs);
+        hipLaunchKernelGGL(rroi_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.cnt, ws.off, P);
+        hipLaunchKernelGGL(rroi_bwd_pairs_kernel<true>, dim3(pblocks), dim3(256), 0, stream, ws.aff,
+                           num_rois, height, width, pooled_width, NB, batch_size, lines_per_roi, dnb,
+                           dpw, ws.cnt, ws.off, ws.pairs);
+        // (2) top_diff (R, C, NB) -> chunk-major (R, nchunks, NB + 1, 32): the forward's relayout
+        //     with R "images" of PH x PW "pixels" (no zero pixels, no affine blocks)
+        {
+            const int tt = ceil_div(NB, kRelayoutPx);
+            const long tiles = (long)tt * nchunks * num_rois;
+            if (tiles >= (1L << 31)) return 0;
+            long blocks = tiles;
+            const long cap = (long)num_cus() * 8;
+            if (blocks > cap) {
+                long unit = nchunks;
+                while (unit % 8) unit += nchunks;
+                blocks = cap >= unit ? cap / unit * unit : cap;
+            }
+            hipLaunchKernelGGL(rroi_prologue_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, top_diff,
+                               ws.tdT, channels, NB, pooled_width, pooled_width,
+                               make_fastdiv((unsigned)pooled_width), nchunks, tt, (int)blocks, (int)tiles,
+                               0, num_rois, (const float*)nullptr, 0, pooled_height, spatial_scale,
+                               (Affine*)nullptr);
+        }
+        st = launch_status();
+        if (st != 1) return st;
+        // (3) gather
+        unsigned sub_shift = 3;  // 8 lanes = one chunk
+        while ((1u << sub_shift) < 8u * (unsigned)nchunks && sub_shift < 6) ++sub_shift;
+        const unsigned groups_per_block = 256u >> sub_shift;
+        long gblocks = ceil_div((long)P, (long)groups_per_block);
+        const long gcap = (long)num_cus() * 8;  // 8 blocks = 32 waves per CU
+        if (gblocks > gcap) gblocks = gcap;
+        hipLaunchKernelGGL(rroi_bwd_gather_kernel, dim3((unsigned)gblocks), dim3(256), 0, stream, ws.tdT,
+                           ws.off, ws.pairs, ws.gcm, channels, height, width, pitch, batch_size, nchunks,
+                           lines_per_chunk, sub_shift, make_fastdiv((unsigned)HW),
+                           make_fastdiv((unsigned)width));
+        st = launch_status();
+        if (st != 1) return st;
+    } else {
+        hipError_t e = hipMemsetAsync(ws.gcm, 0, (size_t)batch_size * nchunks * height * pitch * kLineBytes, stream);
+        if (e != hipSuccess) return status_of(e);
+        const int ntiles = ceil_div(NB, kTileBins);
+        if ((long)num_rois * ntiles >= (1L << 31)) return 0;
+        const int grid = tiled_grid((long)num_rois * ntiles, nchunks);
+        const FastDiv dt = make_fastdiv((unsigned)ntiles), dp = make_fastdiv((unsigned)pooled_width);
+        if (NB % 4 == 0)
+            hipLaunchKernelGGL(rroi_bwd_tiled_kernel<true>, dim3(grid), dim3(kWave), 0, stream,
+                               top_diff, ws.aff, ws.gcm, num_rois, channels, height, width, pitch,
+                               pooled_width, NB, batch_size, nchunks, ntiles, dt, dp);
+        else
+            hipLaunchKernelGGL(rroi_bwd_tiled_kernel<false>, dim3(grid), dim3(kWave), 0, stream,
+                               top_diff, ws.aff, ws.gcm, num_rois, channels, height, width, pitch,
+                               pooled_width, NB, batch_size, nchunks, ntiles, dt, dp);
+        st = launch_status();
+        if (st != 1) return st;
+    }
     hipLaunchKernelGGL(rroi_cm_to_nchw_kernel, dim3(ptiles * nchunks * batch_size), dim3(256), 0,
-                       stream, ws.cm, bottom_diff, channels, (int)HW, width, pitch,
+                       stream, ws.gcm, bottom_diff, channels, (int)HW, width, pitch,
                        make_fastdiv((unsigned)width), nchunks, ptiles);
     return launch_status();
 }

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librroi_align_hip.so")
 
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
-PATH_AUTO, PATH_DIRECT, PATH_TILED = 0, 1, 2
+PATH_AUTO, PATH_DIRECT, PATH_TILED, PATH_TILED_ATOMIC = 0, 1, 2, 3
 STAGE_PROLOGUE, STAGE_GATHER, STAGE_ALL = 1, 2, 3
 
 if not os.path.exists(LIB_PATH):
@@ -38,7 +38,7 @@ _lib.rroi_align_hip_version.restype = ctypes.c_char_p
 _lib.rroi_align_forward_workspace_bytes.restype = _sz
 _lib.rroi_align_forward_workspace_bytes.argtypes = [_i] * 6
 _lib.rroi_align_backward_workspace_bytes.restype = _sz
-_lib.rroi_align_backward_workspace_bytes.argtypes = [_i] * 5
+_lib.rroi_align_backward_workspace_bytes.argtypes = [_i] * 7
 _lib.rroi_align_forward_hip.restype = _i
 _lib.rroi_align_forward_hip.argtypes = [_vp, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]
 _lib.rroi_align_forward_stages_hip.restype = _i
@@ -143,7 +143,7 @@ def backward(grad_output: torch.Tensor, rois: torch.Tensor, feature_size, spatia
         grad_in = torch.empty((B, C, H, W), dtype=torch.float32, device=grad_output.device)
         if grad_in.numel() == 0:
             return grad_in
-        nbytes = 0 if path == PATH_DIRECT else _lib.rroi_align_backward_workspace_bytes(B, C, H, W, R)
+        nbytes = 0 if path == PATH_DIRECT else _lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, ph, pw)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=grad_output.device)
         st = _lib.rroi_align_backward_hip(grad_output.data_ptr(), float(spatial_scale), B, R, H, W,
                                           C, ph, pw, rois.data_ptr(), grad_in.data_ptr(),

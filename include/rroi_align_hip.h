@@ -67,13 +67,15 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
 #define RROI_PATH_AUTO 0   /* pick by problem size                                  */
 #define RROI_PATH_DIRECT 1 /* one kernel, NCHW gather, no workspace (small R)       */
 #define RROI_PATH_TILED 2  /* relayout to pixel-major + wave-tiled gather (large R) */
+#define RROI_PATH_TILED_ATOMIC 3 /* backward only: the tiled scatter with fp32 atomics (the
+                                    default tiled backward is an atomic-free gather)         */
 
 /* Bytes of scratch the tiled path needs for this problem (0 for the direct
  * path).  The caller owns the scratch; its contents are dead after the call. */
 size_t rroi_align_forward_workspace_bytes(int batch_size, int channels, int height, int width,
                                           int num_rois, int feature_layout);
 size_t rroi_align_backward_workspace_bytes(int batch_size, int channels, int height, int width,
-                                           int num_rois);
+                                           int num_rois, int pooled_height, int pooled_width);
 
 /* Forward.  top_data (R, C, PH, PW) is fully written.  rois whose batch index
  * falls outside [0, batch_size) produce zeros (the reference reads out of

@@ -69,9 +69,10 @@ def test_cfg3_forward_backward(ext, oracle, full):
     g1 = ext.backward(pooled.detach() * 2, rois, f.shape, 0.25)
     g2 = ext.backward(pooled.detach() * 4, rois, f.shape, 0.25)
     assert torch.allclose(g2, 2 * g1, rtol=1e-4, atol=1e-4 * scale)
-    # direct and tiled backward agree
-    gd = ext.backward(pooled.detach() * 2, rois, f.shape, 0.25, path=ext.PATH_DIRECT)
-    assert (gd - g1).abs().max().item() <= 1e-4 * scale
+    # direct, tiled (gather) and tiled-atomic (scatter) backward agree
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED_ATOMIC):
+        gd = ext.backward(pooled.detach() * 2, rois, f.shape, 0.25, path=p)
+        assert (gd - g1).abs().max().item() <= 1e-4 * scale
 
 
 def test_cfg4_shard_of_4096(ext, oracle):

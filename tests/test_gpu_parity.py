@@ -118,7 +118,7 @@ def test_golden_fixtures(ext, name):
     geom = ext.bin_centres(dev(z["rois"]), ph, pw, s, H, W).cpu().numpy()
     assert eq(geom, z["geom"])
     gout = (2.0 * np.nan_to_num(z["out"])).astype(np.float32)
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_ATOMIC):
         gin = ext.backward(dev(gout), dev(z["rois"]), z["features"].shape, s, path=p).cpu().numpy()
         scale = max(1.0, float(np.abs(z["grad_in"]).max()))
         assert np.abs(gin - z["grad_in"]).max() <= BWD_RTOL * scale
@@ -139,14 +139,14 @@ def test_sincos_recipe_matches_host_libm(ext):
     assert bad == 0, f"{bad} of {2 * len(deg)} sin/cos values differ between ocml and glibc"
 
 
-@pytest.mark.parametrize("path", ["direct", "tiled"])
+@pytest.mark.parametrize("path", ["direct", "tiled", "tiled_atomic"])
 @pytest.mark.parametrize("name", ["cfg1", "mid_c64", "c70_odd", "c5_pad", "batch3", "train_11xceil"])
 def test_backward_vs_oracle(ext, oracle, name, path):
     f, r, ph, pw, s = SHAPES[name]()
     out = oracle.forward_c(f, r, ph, pw, s, threads=8)
     gout = (2 * out).astype(np.float32)
     want = oracle.backward_c(gout, r, f.shape, s)
-    p = ext.PATH_DIRECT if path == "direct" else ext.PATH_TILED
+    p = {"direct": ext.PATH_DIRECT, "tiled": ext.PATH_TILED, "tiled_atomic": ext.PATH_TILED_ATOMIC}[path]
     got = ext.backward(dev(gout), dev(r), f.shape, s, path=p).cpu().numpy()
     scale = max(1.0, float(np.abs(want).max()))
     assert np.abs(got - want).max() <= BWD_RTOL * scale
@@ -159,9 +159,29 @@ def test_backward_edge_rois(ext, oracle):
     rois = np.concatenate([Wk.edge_rois(), Wk.degenerate_rois()[[0, 1, 2, 3, 4]]])
     gout = rng.standard_normal((len(rois), 8, 8, 64), dtype=np.float32)
     want = oracle.backward_c(gout, rois, f.shape, 0.25)
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_ATOMIC):
         got = ext.backward(dev(gout), dev(rois), f.shape, 0.25, path=p).cpu().numpy()
         assert np.abs(got - want).max() <= BWD_RTOL * max(1.0, float(np.abs(want).max()))
+
+
+def test_backward_nonfinite_gradients(ext, oracle):
+    """The reference sends w*g AND 0*g to a pixel that two taps of a bin alias (kernel.cu:260-274):
+    an infinite g there makes the pixel NaN, not inf.  Same set of non-finite pixels on every path;
+    the finite ones within tolerance."""
+    f, r = Wk.bench_inputs(R=24, C=8, seed=17)
+    rng = np.random.default_rng(17)
+    gout = rng.standard_normal((24, 8, 8, 64), dtype=np.float32)
+    sel = rng.random(gout.shape)
+    gout[sel < 0.002] = np.inf
+    gout[(sel >= 0.002) & (sel < 0.003)] = np.nan
+    want = oracle.backward_c(gout, r, f.shape, 0.25)
+    assert np.isnan(want).any()
+    fin = np.isfinite(want)
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_ATOMIC):
+        got = ext.backward(dev(gout), dev(r), f.shape, 0.25, path=p).cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(want)), f"path {p}"
+        assert np.array_equal(np.isposinf(got), np.isposinf(want)) and np.array_equal(np.isneginf(got), np.isneginf(want))
+        assert np.abs(got[fin] - want[fin]).max() <= BWD_RTOL * max(1.0, float(np.abs(want[fin]).max()))
 
 
 def test_autograd_surface(ext, oracle):
@@ -281,7 +301,7 @@ def test_random_shape_sweep(ext, oracle):
             assert n == 0, f"trial {trial} C={C} {H}x{W} B={B} {ph}x{pw} s={s} R={R} path={p}: {n} differ (max {d})"
         gout = np.random.default_rng(trial).standard_normal(want.shape).astype(np.float32)
         gwant = oracle.backward_c(gout, r, f.shape, s)
-        for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+        for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_ATOMIC):
             g = ext.backward(dev(gout), dev(r), f.shape, s, path=p).cpu().numpy()
             assert np.abs(g - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max())), f"trial {trial} bwd path={p}"
 

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Backward at BASELINE cfg3 sizes, 20 calls -- run under `rocprofv3 --kernel-trace --stats`."""
+"""Backward at BASELINE cfg3 sizes: wall time per call of every path, then 20 calls of the default
+tiled path -- run under `rocprofv3 --kernel-trace --stats` for the per-kernel split."""
 import os
 import sys
+import time
 
 import torch
 
@@ -13,6 +15,29 @@ from rroi_align._ext import rroi_align as ext  # noqa: E402
 f, r = Wk.bench_inputs()
 R = torch.from_numpy(r).cuda()
 g = torch.randn(512, 256, 8, 64, device="cuda")
+B, C, H, W = f.shape
+nb = ext._lib.rroi_align_backward_workspace_bytes(B, C, H, W, 512, 8, 64)
+ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+gin = torch.empty((B, C, H, W), device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+
+
+def call(path):
+    rc = ext._lib.rroi_align_backward_hip(g.data_ptr(), 0.25, B, 512, H, W, C, 8, 64, R.data_ptr(),
+                                          gin.data_ptr(), ws.data_ptr(), nb, path, st)
+    assert rc == 1, rc
+
+
+for name, path, n in (("tiled (gather)", ext.PATH_TILED, 50), ("tiled_atomic (scatter)", ext.PATH_TILED_ATOMIC, 20),
+                      ("direct", ext.PATH_DIRECT, 5)):
+    for _ in range(3):
+        call(path)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        call(path)
+    torch.cuda.synchronize()
+    print(f"backward cfg3 {name}: {(time.perf_counter() - t0) / n * 1e6:.1f} us  (workspace {nb / 1e6:.1f} MB)")
 for _ in range(20):
-    ext.backward(g, R, f.shape, 0.25, path=ext.PATH_TILED)
+    call(ext.PATH_TILED)
 torch.cuda.synchronize()

@@ -72,6 +72,42 @@ res["fwd_all"] = timeit(lambda: stage(3), iters=100)
 res["fwd_direct"] = timeit(lambda: stage(2, ext.PATH_DIRECT), iters=20)
 ours = out.clone()
 
+# sensitivity points of SURVEY.md 8(d): same map, ROI set varied (gather kernel only, 300 launches)
+def variant(name, mod):
+    rv = rois.copy()
+    mod(rv)
+    Rv = torch.from_numpy(rv).to(dev)
+
+    def run():
+        rc = ext._lib.rroi_align_forward_stages_hip(F.data_ptr(), 0, 0.25, 1, 512, 160, 160, 256, 8, 64,
+                                                     Rv.data_ptr(), out.data_ptr(), ws.data_ptr(), nb,
+                                                     ext.PATH_TILED, 2, st)
+        assert rc == 1, rc
+    rc = ext._lib.rroi_align_forward_stages_hip(F.data_ptr(), 0, 0.25, 1, 512, 160, 160, 256, 8, 64, Rv.data_ptr(),
+                                                 out.data_ptr(), ws.data_ptr(), nb, ext.PATH_TILED, 1, st)
+    assert rc == 1, rc
+    r = timeit(run, iters=300, warm=100)
+    r["active_bin_fraction"] = float((out[:, 0] != 0).float().mean().item())
+    res["fwd_gather_" + name] = r
+
+
+def _all_active(rv): rv[:, 4] = rv[:, 3] * 8.0           # w/h = 8: roi_pooled_width = 64, no masked bins
+def _axis(rv): rv[:, 5] = 0.0
+def _vertical(rv): rv[:, 5] = 90.0
+def _inside(rv):                                            # every box well inside the map
+    rv[:, 1] = 200 + (rv[:, 1] % 240)
+    rv[:, 2] = 200 + (rv[:, 2] % 240)
+    rv[:, 3] = np.minimum(rv[:, 3], 32)
+    rv[:, 4] = np.minimum(rv[:, 4], 200)
+
+
+variant("bench_rois", lambda rv: None)
+variant("all_active_w_over_h_8", _all_active)
+variant("axis_aligned_angle_0", _axis)
+variant("vertical_angle_90", _vertical)
+variant("all_inside_map", _inside)
+stage(1)
+
 Fcl = F.contiguous(memory_format=torch.channels_last)
 res["fwd_channels_last_zero_copy"] = timeit(lambda: ext.forward(Fcl, R, 8, 64, 0.25))
 
