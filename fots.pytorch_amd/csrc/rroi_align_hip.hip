@@ -277,32 +277,25 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned by
 // ------------------------------------------------------------------------------------
 constexpr int kRelayoutPx = 128;
 
-template <int AUX>
-__global__ __launch_bounds__(256) void rroi_prologue_kernel(
-    const float* __restrict__ nchw, float* __restrict__ cm, int C, int HW, int width, int pitch,
-    FastDiv div_w, int nchunks, int ptiles, int relayout_blocks, int relayout_tiles, int zero_blocks,
-    int batch_size, const float* __restrict__ rois, int num_rois, int pooled_height,
-    float spatial_scale, Affine* __restrict__ aff)
+// The relayout proper, shared by the forward prologue (feature map) and the backward (top_diff,
+// R "images" of PH x PW "pixels").  MASK: image b is ROI b and pixels (ph, pw) with
+// pw > roi_pooled_width (or every pixel of a ROI with an invalid batch index) are bins the
+// forward masks -- nothing reads them again, so they are neither loaded nor written.
+constexpr int kTP = kRelayoutPx + 4;
+
+template <int AUX, bool MASK>
+__device__ __forceinline__ void relayout_run(float* __restrict__ T, const float* __restrict__ nchw,
+                                               float* __restrict__ cm, int C, int HW, int width, int pitch,
+                                               FastDiv div_w, int nchunks, int ptiles, int first_tile,
+                                               int tile_stride, int relayout_tiles,
+                                               const Affine* __restrict__ mask_aff, int mask_batches)
 {
     // [32 ch][128 px] tile, 132-float pitch (16-byte aligned rows for the b128 writes); the
     // pixel index of rows 8m..8m+7 is XORed with 4m so that the transposed ds_read_b32 of
     // phase 2 (8 channel quads x 4 pixels per 32-lane group) hits 32 different banks.
-    constexpr int kTP = kRelayoutPx + 4;
-    __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
     const int tid = threadIdx.x;
     const size_t zp_index = (size_t)(HW / width) * pitch;  // pixel index of the zero pixel
     const size_t slice_stride = (zp_index + 1) * kChunk;
-    if ((int)blockIdx.x >= relayout_blocks + zero_blocks) {
-        const int n = ((int)blockIdx.x - relayout_blocks - zero_blocks) * 256 + tid;
-        if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
-        return;
-    }
-    if ((int)blockIdx.x >= relayout_blocks) {
-        const int i = ((int)blockIdx.x - relayout_blocks) * 256 + tid;  // (slice, channel-in-chunk)
-        if (i < batch_size * nchunks * kChunk)
-            cm[(size_t)(i / kChunk) * slice_stride + zp_index * kChunk + (i % kChunk)] = 0.0f;
-        return;
-    }
     const int lane = tid & 63, w = tid >> 6;
     // phase 1 mapping: lane -> 4 consecutive pixels (x4) of channel row (csub); a wave
     // instruction reads two 512-byte runs.  phase 2 mapping: lane -> (channel quad, pixel).
@@ -310,6 +303,12 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
     const int cq = lane & 7, pl = lane >> 3;
     // rows of 16-byte aligned float4 (p0 is a multiple of 128): needs HW % 4 == 0 and an aligned base
     const bool vec_ok = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(nchw) & 15) == 0;
+
+    // (MASK) highest live pooled column of image b: pw <= rpw  <=>  pw <= floor(rpw) for integer pw
+    auto live_limit = [&](int b) -> float {
+        const Affine A = mask_aff[b];
+        return (A.batch >= 0 && A.batch < mask_batches) ? A.rpw : -1.0f;
+    };
 
     v4f r[4];
     auto load_tile = [&](int tile) {
@@ -321,12 +320,22 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
         const int b = tile / (ptiles * nchunks);
         const int p0 = pt * kRelayoutPx, c0 = k * kChunk;
         const float* src = nchw + ((size_t)b * C + c0) * HW + p0;
+        const int p = 4 * x4;
+        bool live = true;
+        if (MASK) {
+            // the four pixels of this lane are dead when the first one is (same row), or when the
+            // run starts in a dead tail and ends in the next row's live head: keep it then
+            const unsigned gp = (unsigned)(p0 + p);
+            const unsigned y = fdiv(gp, div_w);
+            const unsigned x = gp - y * (unsigned)width;
+            const float lim = live_limit(b);
+            live = !((float)x > lim) || x + 3u >= (unsigned)width;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = w * 8 + i * 2 + csub;
-            const int p = 4 * x4;
             v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (c0 + c < C) {
+            if (c0 + c < C && live) {
                 const float* sp = src + (size_t)c * HW + p;
                 if (vec_ok && p0 + p + 3 < HW) {
                     v = *reinterpret_cast<const v4f*>(sp);
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
     };
     // grid-stride over tiles, software-pipelined: the loads of the next tile are in flight
     // while the current tile goes through LDS and out to the chunk-major copy
-    int tile = blockIdx.x;
+    int tile = first_tile;
     if (tile < relayout_tiles) load_tile(tile);
     while (tile < relayout_tiles) {
 #pragma unroll
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
         }
         __syncthreads();
         const int cur = tile;
-        tile += relayout_blocks;
+        tile += tile_stride;
         if (tile < relayout_tiles) load_tile(tile);
         {
             const int k = cur % nchunks;
@@ -360,6 +369,7 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
             const int b = cur / (ptiles * nchunks);
             const int p0 = pt * kRelayoutPx;
             float* dst = cm + ((size_t)b * nchunks + k) * slice_stride;
+            const float lim = MASK ? live_limit(b) : 0.0f;
             // wave w writes pixels 32w..32w+31: per instruction 8 pixels x 128 B = 1 KiB contiguous
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -368,8 +378,9 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
                 v4f v = {tr[0], tr[kTP], tr[2 * kTP], tr[3 * kTP]};
                 const unsigned gp = (unsigned)(p0 + p);
                 const unsigned y = fdiv(gp, div_w);
-                const size_t pix = (size_t)y * pitch + (gp - y * (unsigned)width);
-                if (p0 + p < HW) {
+                const unsigned x = gp - y * (unsigned)width;
+                const size_t pix = (size_t)y * pitch + x;
+                if (p0 + p < HW && !(MASK && (float)x > lim)) {
                     if (AUX == 0) {
                         *reinterpret_cast<v4f*>(dst + pix * kChunk + cq * 4) = v;
                     } else {
@@ -381,6 +392,32 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
         }
         __syncthreads();
     }
+}
+
+template <int AUX>
+__global__ __launch_bounds__(256) void rroi_prologue_kernel(
+    const float* __restrict__ nchw, float* __restrict__ cm, int C, int HW, int width, int pitch,
+    FastDiv div_w, int nchunks, int ptiles, int relayout_blocks, int relayout_tiles, int zero_blocks,
+    int batch_size, const float* __restrict__ rois, int num_rois, int pooled_height,
+    float spatial_scale, Affine* __restrict__ aff)
+{
+    __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= relayout_blocks + zero_blocks) {
+        const int n = ((int)blockIdx.x - relayout_blocks - zero_blocks) * 256 + tid;
+        if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+        return;
+    }
+    if ((int)blockIdx.x >= relayout_blocks) {
+        const size_t zp_index = (size_t)(HW / width) * pitch;  // pixel index of the zero pixel
+        const size_t slice_stride = (zp_index + 1) * kChunk;
+        const int i = ((int)blockIdx.x - relayout_blocks) * 256 + tid;  // (slice, channel-in-chunk)
+        if (i < batch_size * nchunks * kChunk)
+            cm[(size_t)(i / kChunk) * slice_stride + zp_index * kChunk + (i % kChunk)] = 0.0f;
+        return;
+    }
+    relayout_run<AUX, false>(T, nchw, cm, C, HW, width, pitch, div_w, nchunks, ptiles, (int)blockIdx.x,
+                               relayout_blocks, relayout_tiles, nullptr, 0);
 }
 
 __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois, int pooled_height,
@@ -785,157 +822,220 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
 // the pair carries an "add 0*g as well" flag (sign bit of the weight) so that both cases are
 // reproduced.
 // ------------------------------------------------------------------------------------
-struct PairGeom {
-    unsigned px[4];   // compact pixel index b*H*W + y*W + x
-    float w[4];       // weight; sign bit set = the reference also adds 0*g to this pixel
-    int n;            // number of pairs of this bin (0..4)
+// Pixel keys of the lists are TILED: a 128-byte line of counters holds an 8 x 4 pixel block
+// (key = ((b*Ht + y/4)*Wt + x/8)*32 + (y%4)*8 + x%8).  Device-scope atomics are bound by the
+// number of line REQUESTS (measured ~10-13 G/s chip-wide, however many lanes a request carries):
+// the 64 bins of a wave lie along a line segment of the map, which crosses ~3x fewer 8 x 4
+// blocks than 32 x 1 row segments.
+struct KeyLayout {
+    unsigned Wt, Ht;   // blocks per row / per column
+    unsigned keys;     // batch * Ht * Wt * 32
 };
 
-__device__ __forceinline__ PairGeom bin_pairs(const Affine& A, unsigned ph, unsigned pw, bool in_range,
-                                              int height, int width, int batch_size)
+__device__ __forceinline__ unsigned pixel_key(const KeyLayout& L, unsigned b, unsigned y, unsigned x)
 {
-    PairGeom g;
-    g.n = 0;
+    return (((b * L.Ht + (y >> 2)) * L.Wt + (x >> 3)) << 5) + ((y & 3u) << 3) + (x & 7u);
+}
+
+// The (pixel, weight) pairs of one bin: the taps that pass kernel.cu:267-274, one pair per
+// DISTINCT pixel.  `emit(key, w)`: w carries the "reference also adds 0*g here" flag in its sign.
+template <class Emit>
+__device__ __forceinline__ void bin_pairs(const Affine& A, unsigned ph, unsigned pw, int height, int width,
+                                          int batch_size, const KeyLayout& L, Emit emit)
+{
     float bcx, bcy;
     bool active = bin_centre(A, (int)ph, (int)pw, height, width, bcx, bcy);
-    active = active && in_range && A.batch >= 0 && A.batch < batch_size;
+    active = active && A.batch >= 0 && A.batch < batch_size;
     const Taps tp = make_taps(bcx, bcy, active, height, width, 1u);
     const unsigned f = tp.flags;
-    if (!(f & kActive)) return g;
+    if (!(f & kActive)) return;
     float wlt, wrt, wrb, wlb;
     tap_weights(tp.rx, tp.ry, wlt, wrt, wrb, wlb);
     const bool dx = f & kDx, dy = f & kDy;
-    const unsigned base = (unsigned)A.batch * (unsigned)(height * width) + tp.o_lt;  // o_lt = y0*W + x0
+    // a passing tap has 0 < x, y < W-1, H-1: the coordinates are small non-negative integers
+    const unsigned x0 = (unsigned)f2i_sat(floorf(bcx)), y0 = (unsigned)f2i_sat(floorf(bcy));
+    const unsigned b = (unsigned)A.batch;
     const float alias = (dx && dy) ? 1.0f : -1.0f;  // not all four taps distinct: some pixel also gets 0*g
-    auto emit = [&](unsigned px, float w) {
-        g.px[g.n] = px;
-        g.w[g.n] = w * alias;  // weights are positive (or NaN, but then every bound has failed)
-        ++g.n;
-    };
-    // kernel.cu:267-274; an aliased tap has the bounds of the tap it aliases
-    if (f & kB00) emit(base, wlt);
-    if (dx && (f & kB01)) emit(base + 1u, wrt);
-    if (dy && (f & kB10)) emit(base + (unsigned)width, wlb);
-    if (dx && dy && (f & kB11)) emit(base + (unsigned)width + 1u, wrb);
-    return g;
+    // an aliased tap has the bounds of the tap it aliases; weights are positive (NaN only when
+    // every bound has failed)
+    if (f & kB00) emit(pixel_key(L, b, y0, x0), wlt * alias);
+    if (dx && (f & kB01)) emit(pixel_key(L, b, y0, x0 + 1u), wrt * alias);
+    if (dy && (f & kB10)) emit(pixel_key(L, b, y0 + 1u, x0), wlb * alias);
+    if (dx && dy && (f & kB11)) emit(pixel_key(L, b, y0 + 1u, x0 + 1u), wrb * alias);
 }
 
-// FILL == false: cnt[pixel] += 1 per pair.  FILL == true: cnt counts back down, handing out the
-// slots of the pixel's segment [off[pixel], off[pixel+1]).
-template <bool FILL>
-__global__ __launch_bounds__(256) void rroi_bwd_pairs_kernel(
-    const Affine* __restrict__ aff, int num_rois, int height, int width, int pooled_width, int NB,
-    int batch_size, unsigned lines_per_roi, FastDiv div_nb, FastDiv div_pw, int* __restrict__ cnt,
-    const unsigned* __restrict__ off, uint2* __restrict__ pairs)
+constexpr unsigned kScanBlock = 4096;  // keys per block of the first scan level
+
+// list offset of key i after the two-level scan
+__device__ __forceinline__ unsigned list_offset(const unsigned* __restrict__ off, const unsigned* __restrict__ bsum, unsigned i)
 {
-    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    return off[i] + bsum[i / kScanBlock];
+}
+
+// FILL == false: cnt[key] += 1 per pair.  FILL == true: cnt counts back down, handing out the
+// slots of the key's segment.
+template <bool FILL>
+__device__ __forceinline__ void pairs_body(unsigned idx, const Affine* __restrict__ aff, int num_rois,
+                                           int height, int width, int pooled_width, int NB, int batch_size,
+                                           unsigned lines_per_roi, FastDiv div_nb, FastDiv div_pw,
+                                           const KeyLayout& L, int* __restrict__ cnt,
+                                           const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
+                                           uint2* __restrict__ pairs)
+{
     const unsigned n = fdiv(idx, div_nb);
     if (n >= (unsigned)num_rois) return;
     const unsigned j = idx - n * (unsigned)NB;
     const unsigned ph = fdiv(j, div_pw);
     const unsigned pw = j - ph * (unsigned)pooled_width;
     const Affine A = aff[n];
-    const PairGeom g = bin_pairs(A, ph, pw, true, height, width, batch_size);
-    for (int i = 0; i < g.n; ++i) {
+    bin_pairs(A, ph, pw, height, width, batch_size, L, [&](unsigned key, float w) {
         if (!FILL) {
-            atomicAdd(cnt + g.px[i], 1);
+            atomicAdd(cnt + key, 1);
         } else {
-            const int slot = atomicAdd(cnt + g.px[i], -1) - 1;
+            const int slot = atomicAdd(cnt + key, -1) - 1;
             // line index of (roi n, bin j) in chunk 0 of the relaid-out top_diff
-            pairs[off[g.px[i]] + (unsigned)slot] = make_uint2(n * lines_per_roi + j, as_u(g.w[i]));
+            pairs[list_offset(off, bsum, key) + (unsigned)slot] = make_uint2(n * lines_per_roi + j, as_u(w));
         }
-    }
+    });
 }
 
-// exclusive scan of cnt[0..P) -> off[0..P], one block; P is the number of map pixels
-__global__ __launch_bounds__(1024) void rroi_scan_kernel(const int* __restrict__ cnt, unsigned* __restrict__ off, unsigned P)
+// One launch, two kinds of blocks: [0, pair_blocks) count (FILL = false) or write (FILL = true)
+// the pair lists -- bound by the atomic request rate -- and the rest relay out tiles
+// [tile_begin, tile_end) of top_diff -- bound by HBM.  They share the chip instead of running
+// one after the other; the host gives each of the two launches half of the tiles.
+template <bool FILL>
+__global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
+    const Affine* __restrict__ aff, int num_rois, int height, int width, int pooled_width, int NB,
+    int batch_size, unsigned lines_per_roi, FastDiv div_nb, FastDiv div_pw, KeyLayout L,
+    int* __restrict__ cnt, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
+    uint2* __restrict__ pairs, int pair_blocks, const float* __restrict__ top_diff,
+    float* __restrict__ tdT, int C, int nchunks, int ptiles, int relayout_blocks, int tile_begin,
+    int tile_end)
+{
+    __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
+    if ((int)blockIdx.x < pair_blocks) {
+        pairs_body<FILL>(blockIdx.x * 256u + threadIdx.x, aff, num_rois, height, width, pooled_width, NB,
+                         batch_size, lines_per_roi, div_nb, div_pw, L, cnt, off, bsum, pairs);
+        return;
+    }
+    relayout_run<0, true>(T, top_diff, tdT, C, NB, pooled_width, pooled_width, div_pw, nchunks, ptiles,
+                          tile_begin + (int)blockIdx.x - pair_blocks, relayout_blocks, tile_end, aff,
+                          batch_size);
+}
+
+// Exclusive scan of cnt[0..N) (N = keys + 1, the last element reads as 0), two levels:
+// level 1: every block scans kScanBlock keys -> off[] (block-local) and its total -> bsum[block];
+// level 2: one block scans the totals in place.  Readers add the two (list_offset).
+__device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned mine, unsigned* wsum, unsigned& total)
+{
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    unsigned incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d, 64);
+        if (lane >= (unsigned)d) incl += o;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned wbase = 0, tot = 0;
+    for (unsigned k = 0; k < 16; ++k) {
+        const unsigned v = wsum[k];
+        if (k < wv) wbase += v;
+        tot += v;
+    }
+    total = tot;
+    __syncthreads();
+    return wbase + incl - mine;
+}
+
+__global__ __launch_bounds__(1024) void rroi_scan1_kernel(const int* __restrict__ cnt, unsigned* __restrict__ off,
+                                                          unsigned* __restrict__ bsum, unsigned keys)
+{
+    __shared__ unsigned wsum[16];
+    const unsigned i0 = blockIdx.x * kScanBlock + threadIdx.x * 4u;
+    unsigned v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = i0 + e < keys ? (unsigned)cnt[i0 + e] : 0u;
+    unsigned total;
+    unsigned run = block_exclusive_scan_1024(v[0] + v[1] + v[2] + v[3], wsum, total);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (i0 + e <= keys) off[i0 + e] = run;
+        run += v[e];
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void rroi_scan2_kernel(unsigned* __restrict__ bsum, unsigned nblocks)
 {
     __shared__ unsigned wsum[16];
     __shared__ unsigned carry_s;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (unsigned base = 0; base < P; base += 4096u) {
-        const unsigned i0 = base + tid * 4u;
-        unsigned v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = i0 + e < P ? (unsigned)cnt[i0 + e] : 0u;
-        const unsigned mine = v[0] + v[1] + v[2] + v[3];
-        unsigned incl = mine;  // inclusive scan over the wave
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned o = __shfl_up(incl, d, 64);
-            if (lane >= (unsigned)d) incl += o;
-        }
-        if (lane == 63) wsum[wv] = incl;
+    for (unsigned base = 0; base < nblocks; base += 1024u) {
+        const unsigned i = base + threadIdx.x;
+        const unsigned v = i < nblocks ? bsum[i] : 0u;
+        unsigned total;
+        const unsigned ex = block_exclusive_scan_1024(v, wsum, total);
+        const unsigned carry = carry_s;
+        if (i < nblocks) bsum[i] = carry + ex;
         __syncthreads();
-        unsigned wbase = 0;
-        for (unsigned k = 0; k < wv; ++k) wbase += wsum[k];
-        unsigned run = carry_s + wbase + incl - mine;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (i0 + e < P) off[i0 + e] = run;
-            run += v[e];
-        }
-        __syncthreads();
-        if (tid == 1023) carry_s = run;
+        if (threadIdx.x == 0) carry_s = carry + total;
         __syncthreads();
     }
-    if (tid == 0) off[P] = carry_s;
 }
 
 // gather: `sub` = 8 * nchunks_pass lanes serve one pixel (lane -> chunk, channel quad); 64 / sub
-// pixels per wave.  The 16-byte loads of eight pairs are in flight together.
+// pixels per wave; one pixel group per thread group, so the hardware's block dispatch balances
+// the (very uneven) list lengths.  The 16-byte loads of eight pairs are in flight together.
 __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
-    const float* __restrict__ tdT, const unsigned* __restrict__ off, const uint2* __restrict__ pairs,
-    float* __restrict__ gcm, int C, int height, int width, int pitch, int batch_size, int nchunks,
-    unsigned lines_per_chunk, unsigned sub_shift, FastDiv div_hw, FastDiv div_w)
+    const float* __restrict__ tdT, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
+    const uint2* __restrict__ pairs, float* __restrict__ gcm, int C, int height, int width, int pitch,
+    int nchunks, unsigned lines_per_chunk, unsigned sub_shift, KeyLayout L, FastDiv div_bt, FastDiv div_wt)
 {
     const unsigned tid = blockIdx.x * 256u + threadIdx.x;
     const unsigned sub = 1u << sub_shift;              // lanes per pixel (8..64)
     const unsigned sl = tid & (sub - 1u);              // lane within the pixel's group
-    const unsigned grp = tid >> sub_shift;             // pixel group id
-    const unsigned ngrp = (gridDim.x * 256u) >> sub_shift;
-    const unsigned HW = (unsigned)height * (unsigned)width;
-    const unsigned P = (unsigned)batch_size * HW;
+    const unsigned key = tid >> sub_shift;
+    if (key >= L.keys) return;
+    // key -> (b, y, x)
+    const unsigned blk = key >> 5, in = key & 31u;
+    const unsigned b = fdiv(blk, div_bt);              // / (Ht*Wt)
+    const unsigned r = blk - b * (L.Ht * L.Wt);
+    const unsigned by = fdiv(r, div_wt);
+    const unsigned y = by * 4u + (in >> 3), x = (r - by * L.Wt) * 8u + (in & 7u);
+    if (y >= (unsigned)height || x >= (unsigned)width) return;  // padding of the key space
+    const unsigned beg = list_offset(off, bsum, key), end = list_offset(off, bsum, key + 1u);
     const unsigned quad = sl & 7u;
     const unsigned slice_px = (unsigned)height * (unsigned)pitch;
     const v4f z4 = {0.f, 0.f, 0.f, 0.f};
     constexpr int kDepth = 8;
-
-    for (unsigned p = grp; p < P; p += ngrp) {
-        const unsigned beg = off[p], end = off[p + 1];
-        const unsigned b = fdiv(p, div_hw);
-        const unsigned yx = p - b * HW;
-        const unsigned y = fdiv(yx, div_w);
-        const unsigned x = yx - y * (unsigned)width;
-        // channel passes of `sub / 8` chunks each (one pass when C <= 256)
-        for (unsigned k0 = 0; k0 < (unsigned)nchunks; k0 += sub >> 3) {
-            const unsigned k = k0 + (sl >> 3);
-            const bool c_ok = k < (unsigned)nchunks && k * kChunk + quad * 4u < (unsigned)C;
-            const float* src = tdT + ((size_t)k * lines_per_chunk) * kChunk + quad * 4u;
-            v4f acc = z4;
-            for (unsigned i = beg; i < end; i += kDepth) {
-                uint2 e[kDepth];
-                v4f g[kDepth];
+    // channel passes of `sub / 8` chunks each (one pass when C <= 256)
+    for (unsigned k0 = 0; k0 < (unsigned)nchunks; k0 += sub >> 3) {
+        const unsigned k = k0 + (sl >> 3);
+        const bool c_ok = k < (unsigned)nchunks && k * kChunk + quad * 4u < (unsigned)C;
+        const float* src = tdT + ((size_t)k * lines_per_chunk) * kChunk + quad * 4u;
+        v4f acc = z4;
+        for (unsigned i = beg; i < end; i += kDepth) {
+            uint2 e[kDepth];
+            v4f g[kDepth];
 #pragma unroll
-                for (int d = 0; d < kDepth; ++d) e[d] = i + d < end ? pairs[i + d] : make_uint2(0u, 0u);
+            for (int d = 0; d < kDepth; ++d) e[d] = i + d < end ? pairs[i + d] : make_uint2(0u, 0u);
 #pragma unroll
-                for (int d = 0; d < kDepth; ++d)
-                    g[d] = (c_ok && i + d < end) ? *reinterpret_cast<const v4f*>(src + (size_t)e[d].x * kChunk) : z4;
+            for (int d = 0; d < kDepth; ++d)
+                g[d] = (c_ok && i + d < end) ? *reinterpret_cast<const v4f*>(src + (size_t)e[d].x * kChunk) : z4;
 #pragma unroll
-                for (int d = 0; d < kDepth; ++d) {
-                    if (i + d < end) {
-                        // kernel.cu:260-263: v_k = w_k * top_diff, then one add per tap
-                        acc += g[d] * as_f(e[d].y & 0x7fffffffu);
-                        if (e[d].y & 0x80000000u) acc += g[d] * 0.0f;
-                    }
+            for (int d = 0; d < kDepth; ++d) {
+                if (i + d < end) {
+                    // kernel.cu:260-263: v_k = w_k * top_diff, then one add per tap
+                    acc += g[d] * as_f(e[d].y & 0x7fffffffu);
+                    if (e[d].y & 0x80000000u) acc += g[d] * 0.0f;
                 }
             }
-            if (c_ok) {
-                float* dst = gcm + (((size_t)b * nchunks + k) * slice_px + (size_t)y * pitch + x) * kChunk + quad * 4u;
-                *reinterpret_cast<v4f*>(dst) = acc;
-            }
+        }
+        if (c_ok) {
+            float* dst = gcm + (((size_t)b * nchunks + k) * slice_px + (size_t)y * pitch + x) * kChunk + quad * 4u;
+            *reinterpret_cast<v4f*>(dst) = acc;
         }
     }
 }
@@ -1371,8 +1471,11 @@ struct BwdWorkspace {
     float* gcm;
     int* cnt;
     unsigned* off;
+    unsigned* bsum;
     uint2* pairs;
     float* tdT;
+    KeyLayout keys;
+    unsigned scan_blocks;
     size_t gcm_bytes, cnt_bytes;
     size_t bytes;
     bool gather_ok;  // the gather formulation's 32-bit indices hold for this problem
@@ -1382,16 +1485,22 @@ BwdWorkspace carve_bwd(void* ws, int batch_size, int channels, int height, int w
 {
     BwdWorkspace w;
     const size_t nchunks = (channels + kChunk - 1) / kChunk;
-    const size_t P = (size_t)batch_size * height * width;
     const size_t R = num_rois > 0 ? num_rois : 1;
+    w.keys.Wt = (unsigned)((width + 7) / 8);
+    w.keys.Ht = (unsigned)((height + 3) / 4);
+    const size_t nkeys = (size_t)batch_size * w.keys.Ht * w.keys.Wt * 32;
+    w.keys.keys = (unsigned)nkeys;
+    w.scan_blocks = (unsigned)((nkeys + 1 + kScanBlock - 1) / kScanBlock);
     const size_t aff_bytes = align_up(R * sizeof(Affine), 256);
     w.gcm_bytes = align_up((size_t)batch_size * nchunks * height * row_pitch(width) * kLineBytes, 256);
-    w.cnt_bytes = align_up(P * sizeof(int), 256);
-    const size_t off_bytes = align_up((P + 1) * sizeof(unsigned), 256);
+    w.cnt_bytes = align_up(nkeys * sizeof(int), 256);
+    const size_t off_bytes = align_up((nkeys + 1) * sizeof(unsigned), 256);
+    const size_t bsum_bytes = align_up((size_t)w.scan_blocks * sizeof(unsigned), 256);
     const size_t pair_bytes = align_up(4 * R * NB * sizeof(uint2), 256);
     const size_t td_bytes = align_up(R * nchunks * ((size_t)NB + 1) * kLineBytes, 256);
-    // pair slots and top_diff line indices are 32-bit
-    w.gather_ok = 4 * R * NB < (1ull << 32) && R * nchunks * ((size_t)NB + 1) < (1ull << 32) && P < (1ull << 31);
+    // pair slots, top_diff line indices and keys are 32-bit; the gather launches one thread group per key
+    w.gather_ok = 4 * R * NB < (1ull << 32) && R * nchunks * ((size_t)NB + 1) < (1ull << 32) &&
+                  nkeys * 64 < (1ull << 40) && nkeys < (1ull << 31);
     char* b = reinterpret_cast<char*>(ws);
     w.aff = reinterpret_cast<Affine*>(b);
     b += aff_bytes;
@@ -1401,11 +1510,14 @@ BwdWorkspace carve_bwd(void* ws, int batch_size, int channels, int height, int w
     b += w.cnt_bytes;
     w.off = reinterpret_cast<unsigned*>(b);
     b += off_bytes;
+    w.bsum = reinterpret_cast<unsigned*>(b);
+    b += bsum_bytes;
     w.pairs = reinterpret_cast<uint2*>(b);
     b += pair_bytes;
     w.tdT = reinterpret_cast<float*>(b);
     b += td_bytes;
-    w.bytes = aff_bytes + w.gcm_bytes + (w.gather_ok ? w.cnt_bytes + off_bytes + pair_bytes + td_bytes : 0);
+    w.bytes = aff_bytes + w.gcm_bytes +
+              (w.gather_ok ? w.cnt_bytes + off_bytes + bsum_bytes + pair_bytes + td_bytes : 0);
     return w;
 }
 
@@ -1648,52 +1760,56 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
 
     if (path != RROI_PATH_TILED_ATOMIC && ws.gather_ok) {
         // (1) pixel -> (bin, weight) lists: count, scan, fill
-        const unsigned P = (unsigned)((size_t)batch_size * HW);
-        hipError_t e = hipMemsetAsync(ws.cnt, 0, (size_t)P * sizeof(int), stream);
+        const KeyLayout KL = ws.keys;
+        hipError_t e = hipMemsetAsync(ws.cnt, 0, (size_t)KL.keys * sizeof(int), stream);
         if (e != hipSuccess) return status_of(e);
         const unsigned lines_per_chunk = (unsigned)NB + 1u;
         const unsigned lines_per_roi = lines_per_chunk * (unsigned)nchunks;
         const int pblocks = ceil_div((long)num_rois * NB, 256);
         const FastDiv dnb = make_fastdiv((unsigned)NB), dpw = make_fastdiv((unsigned)pooled_width);
-        hipLaunchKernelGGL(rroi_bwd_pairs_kernel<false>, dim3(pblocks), dim3(256), 0, stream, ws.aff,
-                           num_rois, height, width, pooled_width, NB, batch_size, lines_per_roi, dnb,
-                           dpw, ws.cnt, ws.off, ws.pairs);
-        hipLaunchKernelGGL(rroi_scan_kernel, dim3(1), dim3(1024), 0, stream, ws.cnt, ws.off, P);
-        hipLaunchKernelGGL(rroi_bwd_pairs_kernel<true>, dim3(pblocks), dim3(256), 0, stream, ws.aff,
-                           num_rois, height, width, pooled_width, NB, batch_size, lines_per_roi, dnb,
-                           dpw, ws.cnt, ws.off, ws.pairs);
-        // (2) top_diff (R, C, NB) -> chunk-major (R, nchunks, NB + 1, 32): the forward's relayout
-        //     with R "images" of PH x PW "pixels" (no zero pixels, no affine blocks)
-        {
-            const int tt = ceil_div(NB, kRelayoutPx);
-            const long tiles = (long)tt * nchunks * num_rois;
-            if (tiles >= (1L << 31)) return 0;
-            long blocks = tiles;
+        // count || first half of the relayout;  scan;  fill || second half.  The relayout is the
+        // forward's, with R "images" of PH x PW "pixels" and the masked bins skipped:
+        // top_diff (R, C, NB) -> chunk-major (R, nchunks, NB + 1, 32)
+        const int tt = ceil_div(NB, kRelayoutPx);
+        const long tiles = (long)tt * nchunks * num_rois;
+        if (tiles >= (1L << 31)) return 0;
+        long unit = nchunks;
+        while (unit % 8) unit += nchunks;  // whole groups of chunks per launch and per grid step
+        const long half = (tiles / 2 + unit - 1) / unit * unit < tiles ? (tiles / 2 + unit - 1) / unit * unit : tiles;
+        auto relayout_grid = [&](long n) {
             const long cap = (long)num_cus() * 8;
-            if (blocks > cap) {
-                long unit = nchunks;
-                while (unit % 8) unit += nchunks;
-                blocks = cap >= unit ? cap / unit * unit : cap;
-            }
-            hipLaunchKernelGGL(rroi_prologue_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, top_diff,
-                               ws.tdT, channels, NB, pooled_width, pooled_width,
-                               make_fastdiv((unsigned)pooled_width), nchunks, tt, (int)blocks, (int)tiles,
-                               0, num_rois, (const float*)nullptr, 0, pooled_height, spatial_scale,
-                               (Affine*)nullptr);
+            if (n <= cap) return n;
+            return cap >= unit ? cap / unit * unit : cap;
+        };
+        {
+            const long blocks = relayout_grid(half);
+            hipLaunchKernelGGL(rroi_bwd_pairs_relayout_kernel<false>, dim3((unsigned)(pblocks + blocks)),
+                               dim3(256), 0, stream, ws.aff, num_rois, height, width, pooled_width, NB,
+                               batch_size, lines_per_roi, dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs,
+                               pblocks, top_diff, ws.tdT, channels, nchunks, tt, (int)blocks, 0, (int)half);
+        }
+        hipLaunchKernelGGL(rroi_scan1_kernel, dim3(ws.scan_blocks), dim3(1024), 0, stream, ws.cnt, ws.off,
+                           ws.bsum, KL.keys);
+        hipLaunchKernelGGL(rroi_scan2_kernel, dim3(1), dim3(1024), 0, stream, ws.bsum, ws.scan_blocks);
+        {
+            const long blocks = relayout_grid(tiles - half);
+            hipLaunchKernelGGL(rroi_bwd_pairs_relayout_kernel<true>, dim3((unsigned)(pblocks + blocks)),
+                               dim3(256), 0, stream, ws.aff, num_rois, height, width, pooled_width, NB,
+                               batch_size, lines_per_roi, dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs,
+                               pblocks, top_diff, ws.tdT, channels, nchunks, tt, (int)blocks, (int)half,
+                               (int)tiles);
         }
         st = launch_status();
         if (st != 1) return st;
-        // (3) gather
+        // (3) gather: one thread group per key, no grid-stride
         unsigned sub_shift = 3;  // 8 lanes = one chunk
         while ((1u << sub_shift) < 8u * (unsigned)nchunks && sub_shift < 6) ++sub_shift;
         const unsigned groups_per_block = 256u >> sub_shift;
-        long gblocks = ceil_div((long)P, (long)groups_per_block);
-        const long gcap = (long)num_cus() * 8;  // 8 blocks = 32 waves per CU
-        if (gblocks > gcap) gblocks = gcap;
+        const long gblocks = ceil_div((long)KL.keys, (long)groups_per_block);
         hipLaunchKernelGGL(rroi_bwd_gather_kernel, dim3((unsigned)gblocks), dim3(256), 0, stream, ws.tdT,
-                           ws.off, ws.pairs, ws.gcm, channels, height, width, pitch, batch_size, nchunks,
-                           lines_per_chunk, sub_shift, make_fastdiv((unsigned)HW),
-                           make_fastdiv((unsigned)width));
+                           ws.off, ws.bsum, ws.pairs, ws.gcm, channels, height, width, pitch, nchunks,
+                           lines_per_chunk, sub_shift, KL, make_fastdiv(KL.Ht * KL.Wt),
+                           make_fastdiv(KL.Wt));
         st = launch_status();
         if (st != 1) return st;
     } else {
