@@ -87,7 +87,7 @@ def variant(name, mod):
                                                  out.data_ptr(), ws.data_ptr(), nb, ext.PATH_TILED, 1, st)
     assert rc == 1, rc
     r = timeit(run, iters=300, warm=100)
-    r["active_bin_fraction"] = float((out[:, 0] != 0).float().mean().item())
+    r["nonzero_bin_fraction"] = float((out[:, 0] != 0).float().mean().item())
     res["fwd_gather_" + name] = r
 
 

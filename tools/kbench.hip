@@ -264,6 +264,16 @@ int main(int argc, char** argv)
         };
         for (int i = 0; i < 300; ++i) stage(3);  // clocks
         CK(hipDeviceSynchronize());
+        for (int aux : {2, 16, 0}) {
+            rroi_align_debug_set_store_aux(aux);
+            char nm[96];
+            snprintf(nm, 96, "gather, store aux=%d", aux);
+            report(nm, T.us([&] { stage(2); }, 100), MB);
+            const double pipe = T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 10, 2) / 20;
+            snprintf(nm, 96, "pipeline step, store aux=%d", aux);
+            report(nm, pipe, MB);
+        }
+        rroi_align_debug_set_store_aux(2);
         for (int wpc : {8, 12}) {
             rroi_align_debug_set_waves_per_cu(wpc);
             for (int dbg : {0, 1, 2, 3}) {
