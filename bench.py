@@ -64,12 +64,18 @@ def cpu_baseline(feats, rois):
         t0 = time.perf_counter()
         O.forward_c(feats, rois, c["PH"], c["PW"], c["scale"], threads=cores)
         best = min(best, time.perf_counter() - t0)
+    # the reference's own structure (one "thread" per output element, geometry recomputed for
+    # every channel, kernel.cu:28-162), single thread, 4 of the 512 ROIs
+    t0 = time.perf_counter()
+    O.forward_literal_c(feats, rois[:4], c["PH"], c["PW"], c["scale"])
+    t_lit = (time.perf_counter() - t0) / 4.0
     touched = O.touched_pixels(rois, 1, c["H"], c["W"], c["PH"], c["PW"], c["scale"])
     return {
         "value": round(len(rois) / best, 1), "unit": "ROIs/s", "cores": cores, "kind": "port",
         "sample": "full workload (512 ROIs x 256 ch x 8x64), oracle/rroi_align_oracle.c hoisted "
                   "forward, OpenMP over ROIs, best of 6; single-thread (128-ROI sample x4): "
-                  "%.1f ROIs/s" % (len(rois) / t1),
+                  "%.1f ROIs/s; literal per-element form of the reference kernel, single thread "
+                  "(4-ROI sample): %.1f ROIs/s" % (len(rois) / t1, 1.0 / t_lit),
         "ms_per_step": round(best * 1e3, 2),
     }, touched
 
@@ -158,6 +164,19 @@ def main():
     pro_ms = np.array([e0.elapsed_time(e1) for e0, e1, _ in ev])
     gat_ms = np.array([e1.elapsed_time(e2) for _, e1, e2 in ev])
 
+    # calibration of the bound on this box: a plain device fill of the same 256 MiB output buffer
+    cal = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
+    for _ in range(10):
+        out.fill_(0.0)
+    cal[0].record()
+    for i in range(40):
+        out.fill_(0.0)
+        cal[i + 1].record()
+    torch.cuda.synchronize()
+    fill_ms = float(np.median([cal[i].elapsed_time(cal[i + 1]) for i in range(40)]))
+    launch(ext.STAGE_ALL)  # leave the real result in `out`
+    torch.cuda.synchronize()
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -200,7 +219,10 @@ def main():
                      "kernel_ms": {"avg": round(gat_avg, 5), "p10": round(float(np.percentile(gat_ms, 10)), 5),
                                    "p50": round(float(np.median(gat_ms)), 5),
                                    "p90": round(float(np.percentile(gat_ms, 90)), 5)},
-                     "prologue_ms_avg": round(float(pro_ms.mean()), 5)},
+                     "prologue_ms_avg": round(float(pro_ms.mean()), 5),
+                     "calibrated": {"what": "torch fill_ of the 256 MiB output buffer on this GPU (median of 40)",
+                                    "GB/s": round(out.numel() * 4 / (fill_ms * 1e-3) / 1e9, 1),
+                                    "frac_of_it": round(achieved / (out.numel() * 4 / (fill_ms * 1e-3) / 1e9), 4)}},
         "cpu_baseline": cpu,
     }
     print(json.dumps(line))
