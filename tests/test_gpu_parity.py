@@ -164,6 +164,33 @@ def test_backward_edge_rois(ext, oracle):
         assert np.abs(got - want).max() <= BWD_RTOL * max(1.0, float(np.abs(want).max()))
 
 
+def test_more_than_256_channels(ext, oracle):
+    """C = 300: ten channel chunks -- the forward's chunk loop leaves the one-chunk-per-XCD regime
+    and the gather backward needs a second channel pass (64 lanes cover 8 chunks)."""
+    f, r = Wk.bench_inputs(R=20, C=300, H=40, W=56, img=224, seed=41, batch=2)
+    want = oracle.forward_c(f, r, 8, 32, 0.25, threads=8)
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+        assert mismatch(run_fwd(ext, f, r, 8, 32, 0.25, p), want)[0] == 0
+    gout = np.random.default_rng(41).standard_normal(want.shape).astype(np.float32)
+    gwant = oracle.backward_c(gout, r, f.shape, 0.25)
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_ATOMIC):
+        g = ext.backward(dev(gout), dev(r), f.shape, 0.25, path=p).cpu().numpy()
+        assert np.abs(g - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max())), f"path {p}"
+
+
+def test_backward_many_rois_on_one_pixel(ext, oracle):
+    """200 identical ROIs: every touched pixel's list holds 200 x its pairs (long lists, the
+    counters' hot spots) and untouched pixels must come out exactly zero."""
+    f, r = Wk.bench_inputs(R=1, C=16, H=48, W=48, img=192, seed=43)
+    r = np.repeat(r, 200, axis=0)
+    gout = np.random.default_rng(43).standard_normal((200, 16, 8, 64)).astype(np.float32)
+    gwant = oracle.backward_c(gout, r, f.shape, 0.25)
+    for p in (ext.PATH_TILED, ext.PATH_TILED_ATOMIC):
+        g = ext.backward(dev(gout), dev(r), f.shape, 0.25, path=p).cpu().numpy()
+        assert np.abs(g - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max()))
+        assert np.array_equal(g == 0, gwant == 0)
+
+
 def test_backward_nonfinite_gradients(ext, oracle):
     """The reference sends w*g AND 0*g to a pixel that two taps of a bin alias (kernel.cu:260-274):
     an infinite g there makes the pixel NaN, not inf.  Same set of non-finite pixels on every path;
