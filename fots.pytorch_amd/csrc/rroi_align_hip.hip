@@ -1338,6 +1338,55 @@ __global__ void rroi_bin_centres_kernel(const float* __restrict__ rois, float* _
     geom[gid * 2 + 1] = in_rroi ? bcy : 0.0f;
 }
 
+// ------------------------------------------------------------------------------------
+// Greedy CTC decode of the recognition logits that the crops turn into:
+// tools/ocr_utils.py:183-186 takes `labels_pred.max(1)` -- arg max over the class axis of
+// (N, nclass, T) -- and src/utils.py:87-97 keeps label t iff it is not the blank (0) and differs
+// from label t-1.  One wave per sequence, lanes = time steps (the class loop reads rows that
+// are contiguous in t); arg max = first index of the largest value, NaN counting as largest
+// (torch.max); the kept labels are compacted with a ballot + popcount prefix.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void rroi_ctc_greedy_kernel(
+    const float* __restrict__ logits, int nclass, int T, const int* __restrict__ lengths,
+    int* __restrict__ labels, int* __restrict__ decoded, int* __restrict__ decoded_len)
+{
+    const unsigned n = blockIdx.x, lane = threadIdx.x;
+    int len = lengths ? lengths[n] : T;
+    len = len < 0 ? 0 : (len > T ? T : len);
+    const float* row = logits + (size_t)n * nclass * T;
+    int* lab = labels ? labels + (size_t)n * T : nullptr;
+    int* dec = decoded + (size_t)n * T;
+    unsigned out = 0;
+    int prev_last = -1;  // label of time step t0 - 1 (none before the first)
+    for (int t0 = 0; t0 < T; t0 += kWave) {
+        const int t = t0 + (int)lane;
+        int best = 0;
+        if (t < T) {
+            float bv = row[t];
+            bool bnan = bv != bv;
+            for (int k = 1; k < nclass; ++k) {
+                const float v = row[(size_t)k * T + t];
+                const bool vnan = v != v;
+                if (!bnan && (vnan || v > bv)) {
+                    bv = v;
+                    best = k;
+                    bnan = vnan;
+                }
+            }
+            if (lab) lab[t] = best;
+        }
+        int prev = __shfl_up(best, 1, kWave);
+        if (lane == 0) prev = prev_last;
+        const bool keep = t < len && best != 0 && best != prev;
+        const unsigned long long m = __ballot(keep);
+        if (keep) dec[out + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = best;
+        out += (unsigned)__popcll(m);
+        prev_last = __shfl(best, kWave - 1, kWave);
+    }
+    for (unsigned i = out + lane; i < (unsigned)T; i += kWave) dec[i] = 0;  // padding
+    if (lane == 0) decoded_len[n] = (int)out;
+}
+
 __global__ void rroi_sincos_probe_kernel(const float* __restrict__ deg, int n, float* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1866,6 +1915,20 @@ int rroi_align_quads_to_rois_hip(const float* quads, const float* batch_index, i
     if (!quads || !rois) return 0;
     hipLaunchKernelGGL(rroi_quads_to_rois_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, quads,
                        batch_index, n, mode, target_h, rois, target_gw);
+    return launch_status();
+}
+
+int rroi_ctc_greedy_decode_hip(const float* logits, int num_seqs, int num_classes, int num_steps,
+                               const int* lengths, int* labels, int* decoded, int* decoded_len,
+                               void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (num_seqs < 0 || num_classes <= 0 || num_steps < 0) return 0;
+    if ((long)num_seqs * num_classes * (long)num_steps >= (1L << 40)) return 0;
+    if (num_seqs == 0) return 1;
+    if (!decoded_len || (num_steps > 0 && (!logits || !decoded))) return 0;
+    hipLaunchKernelGGL(rroi_ctc_greedy_kernel, dim3(num_seqs), dim3(kWave), 0, stream, logits,
+                       num_classes, num_steps, lengths, labels, decoded, decoded_len);
     return launch_status();
 }
 

@@ -49,6 +49,8 @@ _lib.rroi_align_bin_centres_hip.restype = _i
 _lib.rroi_align_bin_centres_hip.argtypes = [_f, _i, _i, _i, _i, _i, _vp, _vp, _vp]
 _lib.rroi_align_quads_to_rois_hip.restype = _i
 _lib.rroi_align_quads_to_rois_hip.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]
+_lib.rroi_ctc_greedy_decode_hip.restype = _i
+_lib.rroi_ctc_greedy_decode_hip.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.rroi_align_sincos_probe_hip.restype = _i
 _lib.rroi_align_sincos_probe_hip.argtypes = [_vp, _i, _vp, _vp]
 _lib.RROIAlignForwardLaucher.restype = _i
@@ -61,6 +63,7 @@ EXPORTS = (
     "rroi_align_backward_hip", "rroi_align_forward_stages_hip", "rroi_align_forward_workspace_bytes",
     "rroi_align_backward_workspace_bytes", "rroi_align_bin_centres_hip",
     "rroi_align_sincos_probe_hip", "rroi_align_quads_to_rois_hip", "rroi_align_hip_version",
+    "rroi_ctc_greedy_decode_hip",
 )
 
 
@@ -166,6 +169,34 @@ def bin_centres(rois: torch.Tensor, pooled_height: int, pooled_width: int, spati
                                              rois.data_ptr(), geom.data_ptr(), _stream())
     _check(st, "rroi_align_bin_centres_hip")
     return geom
+
+
+def ctc_greedy_decode(logits: torch.Tensor, lengths=None, return_labels: bool = False):
+    """(N, nclass, T) fp32 logits -> (decoded (N, T) int32 zero-padded, decoded_len (N,) int32
+    [, raw arg-max labels (N, T) int32]), all on the device; one launch for all sequences.
+    Replaces `labels_pred.max(1)` + strLabelConverter.decode (tools/ocr_utils.py:183-186)."""
+    _require_cuda_f32(logits, "logits")
+    if logits.dim() != 3:
+        raise ValueError("logits must be (N, nclass, T)")
+    logits = logits.contiguous()
+    N, K, T = logits.shape
+    if K == 0:
+        raise ValueError("logits must have at least one class")
+    with torch.cuda.device_of(logits):
+        dev = logits.device
+        if lengths is not None:
+            lengths = torch.as_tensor(lengths, dtype=torch.int32, device=dev).contiguous()
+            if lengths.numel() != N:
+                raise ValueError("lengths must have one entry per sequence")
+        decoded = torch.empty((N, T), dtype=torch.int32, device=dev)
+        dlen = torch.empty((N,), dtype=torch.int32, device=dev)
+        labels = torch.empty((N, T), dtype=torch.int32, device=dev) if return_labels else None
+        st = _lib.rroi_ctc_greedy_decode_hip(
+            logits.data_ptr(), N, K, T, lengths.data_ptr() if lengths is not None else None,
+            labels.data_ptr() if labels is not None else None, decoded.data_ptr(), dlen.data_ptr(),
+            _stream())
+    _check(st, "rroi_ctc_greedy_decode_hip")
+    return (decoded, dlen, labels) if return_labels else (decoded, dlen)
 
 
 def quads_to_rois(quads: torch.Tensor, batch_index=None, mode: int = 0, target_h: int = 11):

@@ -121,6 +121,20 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
 int rroi_align_quads_to_rois_hip(const float* quads, const float* batch_index, int n, int mode,
                                  int target_h, float* rois, int* target_gw, void* stream);
 
+/* Greedy CTC decode of the recognition logits computed from the crops: replaces the per-box
+ * `labels_pred.max(1)` + Python loop of tools/ocr_utils.py:183-186 / src/utils.py:87-97
+ * (strLabelConverter.decode, raw=False) for all boxes of an image in one launch.
+ *   logits      (num_seqs, num_classes, num_steps) fp32, contiguous -- net.forward_ocr's layout
+ *   lengths     (num_seqs) int32 valid time steps per sequence, or NULL (= num_steps)
+ *   labels      (num_seqs, num_steps) int32 raw arg max per step, or NULL
+ *   decoded     (num_seqs, num_steps) int32: label t is kept iff t < length, it is not the blank
+ *               (0) and it differs from label t-1; kept labels first, then zeros
+ *   decoded_len (num_seqs) int32 number of kept labels
+ * arg max = first index of the largest value; NaN counts as largest (torch.max). */
+int rroi_ctc_greedy_decode_hip(const float* logits, int num_seqs, int num_classes, int num_steps,
+                               const int* lengths, int* labels, int* decoded, int* decoded_len,
+                               void* stream);
+
 /* Bin centres only: geom (R, PH, PW, 2) = (bin_cx, bin_cy), 0 where the bin is
  * outside the ROI's pooled width (kernel.cu:86-107).  Diagnostic / test hook. */
 int rroi_align_bin_centres_hip(float spatial_scale, int num_rois, int height, int width,
