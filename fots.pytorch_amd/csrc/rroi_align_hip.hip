@@ -252,10 +252,14 @@ __device__ __forceinline__ v4f buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_
 // Cache policy of the output stream (gfx940-family bits: 1 = sc0, 2 = nt, 16 = sc1).  The
 // 256 MiB of crops must not displace the 3.3 MB map slice from the XCD's 4 MiB L2: with plain
 // stores every written line is kept in L2 and 47 % of the tap reads missed L2 (gather kernel
-// 61 us).  Both nt (streaming) and sc1 (write-through, line dropped) avoid that: 52.4 / 50.6 us
-// for the kernel alone -- but in the prologue+gather sequence the step takes 60 us with nt
-// against 67 us with sc1 (the write-through traffic is still draining when the next prologue
-// starts), so nt is the default.
+// 59 us).  nt (streaming) and sc1 (write-through, line dropped) both avoid that.  A store-only
+// kernel runs at 49.5 us with nt and 40 us with sc1 -- the nt write path is narrower -- but over
+// a whole step (prologue + gather, the bench's unit) write-through costs more than it saves: it
+// displaces the feature map the next prologue reads (57.1 us with nt, 63.6 us with sc0 sc1).
+// A MIX wins on both counts: one of a tile's eight stores write-through, seven nt -- kernel
+// 46.9 us, step 54.5 us (two of eight: 55.9; one of sixteen: 56.8; the position in the tile is
+// irrelevant).  profiles/r01_micro_store_policy.txt.
+constexpr int kMinorAux = 17;
 template <int AUX>
 __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned byte_off, v4f v)
 {
@@ -640,6 +644,11 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
                 const unsigned off = (r * (unsigned)NB + bin0) * 4u;
                 const v4f o = {a0 ? v[s4].x : 0.f, a1 ? v[s4].y : 0.f, a2 ? v[s4].z : 0.f, a3 ? v[s4].w : 0.f};
                 if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
+                    // AUX == 2 (the shipped policy): the first of the tile's eight stores goes out
+                    // write-through (sc0 sc1), the other seven streaming (nt) -- see buf_store
+                    if (AUX == 2 && hs == 0 && s4 == 0)
+                        buf_store<kMinorAux>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);
+                    else
                     buf_store<AUX>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);
                 } else {
                     buf_store1<AUX>(ws, (live && bin0 + 0 < (unsigned)NB) ? off + 0 : kOOB, o.x);
@@ -1719,6 +1728,7 @@ int rroi_align_forward_stages_hip(const float* features, int feature_layout, flo
         if (NB % 4 != 0) RROI_LAUNCH_FWD(false, 2);
         else if (g_store_aux == 0) RROI_LAUNCH_FWD(true, 0);    // exploration only
         else if (g_store_aux == 16) RROI_LAUNCH_FWD(true, 16);  // exploration only
+        else if (g_store_aux == 3) RROI_LAUNCH_FWD(true, 3);    // exploration only: pure nt (sc0 nt)
         else RROI_LAUNCH_FWD(true, 2);
 #undef RROI_LAUNCH_FWD
     }

@@ -264,7 +264,7 @@ int main(int argc, char** argv)
         };
         for (int i = 0; i < 300; ++i) stage(3);  // clocks
         CK(hipDeviceSynchronize());
-        for (int aux : {2, 16, 0}) {
+        for (int aux : {2, 3, 16, 0}) {
             rroi_align_debug_set_store_aux(aux);
             char nm[96];
             snprintf(nm, 96, "gather, store aux=%d", aux);
