@@ -208,8 +208,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: features 1x256x160x160 fp32 NCHW, %d rotated ROIs/GPU, "
-                               "pooled 8x64, spatial_scale 0.25, forward" % R,
+        "config": {"workload": ("configs[1]" if world == 1 else "configs[3] (%d ROIs sharded over %d GPUs)" % (R * world, world))
+                               + ": features 1x256x160x160 fp32 NCHW%s, %d rotated ROIs/GPU, "
+                               "pooled 8x64, spatial_scale 0.25, forward" % (" replicated" if world > 1 else "", R),
                    "rois_per_gpu": R, "rois_total": R * world, "channels": c["C"],
                    "pooled": [c["PH"], c["PW"]], "path": "prologue(relayout+affine) + tiled gather",
                    "parallelism": "roi-shard x%d, no data-path collective" % world},
