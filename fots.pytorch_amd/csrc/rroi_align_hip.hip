@@ -912,7 +912,7 @@ __device__ __forceinline__ void pairs_body(unsigned idx, const Affine* __restric
 // the pair lists -- bound by the atomic request rate -- and the rest relay out tiles
 // [tile_begin, tile_end) of top_diff -- bound by HBM.  They share the chip instead of running
 // one after the other; the host gives each of the two launches half of the tiles.
-template <bool FILL>
+template <bool FILL, int SAUX>
 __global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
     const Affine* __restrict__ aff, int num_rois, int height, int width, int pooled_width, int NB,
     int batch_size, unsigned lines_per_roi, FastDiv div_nb, FastDiv div_pw, KeyLayout L,
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
                              div_nb, div_pw, L, cnt, off, bsum, pairs);
         return;
     }
-    relayout_run<0, true>(T, top_diff, tdT, C, NB, pooled_width, pooled_width, div_pw, nchunks, ptiles,
+    relayout_run<SAUX, true>(T, top_diff, tdT, C, NB, pooled_width, pooled_width, div_pw, nchunks, ptiles,
                           tile_begin + (int)blockIdx.x - pair_blocks, relayout_blocks, tile_end, aff,
                           batch_size);
 }
@@ -1595,6 +1595,9 @@ int g_store_aux = 2;   // cache policy of the output stores (see buf_store); 16 
 int g_fwd_dbg = 0;     // ablation: 1 = skip output stores, 2 = all taps out of range
 int g_prologue_blocks_per_cu = 3;
 int g_prologue_aux = 0;
+// store policy of the backward's top_diff relayout: streaming (nt) 189.5 us per call, sc1 191.3,
+// plain 194.0 (tools/bwd_profile.py with RROI_BWD_SWEEP=1); non-temporal LOADS in the gather: +16 us
+int g_bwd_relayout_aux = 2;
 
 }  // namespace
 
@@ -1744,6 +1747,12 @@ int rroi_align_debug_set_store_aux(int v)
     g_store_aux = v;
     return old;
 }
+int rroi_align_debug_set_bwd_relayout_aux(int v)
+{
+    const int old = g_bwd_relayout_aux;
+    g_bwd_relayout_aux = v;
+    return old;
+}
 int rroi_align_debug_set_fwd_dbg(int v)
 {
     const int old = g_fwd_dbg;
@@ -1845,24 +1854,27 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
             if (n <= cap) return n;
             return cap >= unit ? cap / unit * unit : cap;
         };
+#define RROI_LAUNCH_PR(FILL, SAUX, BLOCKS, T0, T1)                                                   \
+    hipLaunchKernelGGL((rroi_bwd_pairs_relayout_kernel<FILL, SAUX>), dim3((unsigned)(pblocks + (BLOCKS))), \
+                       dim3(256), 0, stream, ws.aff, num_rois, height, width, pooled_width, NB,          \
+                       batch_size, lines_per_roi, dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs,       \
+                       pblocks, top_diff, ws.tdT, channels, nchunks, tt, (int)(BLOCKS), (int)(T0), (int)(T1))
         {
             const long blocks = relayout_grid(half);
-            hipLaunchKernelGGL(rroi_bwd_pairs_relayout_kernel<false>, dim3((unsigned)(pblocks + blocks)),
-                               dim3(256), 0, stream, ws.aff, num_rois, height, width, pooled_width, NB,
-                               batch_size, lines_per_roi, dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs,
-                               pblocks, top_diff, ws.tdT, channels, nchunks, tt, (int)blocks, 0, (int)half);
+            if (g_bwd_relayout_aux == 16) RROI_LAUNCH_PR(false, 16, blocks, 0, half);
+            else if (g_bwd_relayout_aux == 2) RROI_LAUNCH_PR(false, 2, blocks, 0, half);
+            else RROI_LAUNCH_PR(false, 0, blocks, 0, half);
         }
         hipLaunchKernelGGL(rroi_scan1_kernel, dim3(ws.scan_blocks), dim3(1024), 0, stream, ws.cnt, ws.off,
                            ws.bsum, KL.keys);
         hipLaunchKernelGGL(rroi_scan2_kernel, dim3(1), dim3(1024), 0, stream, ws.bsum, ws.scan_blocks);
         {
             const long blocks = relayout_grid(tiles - half);
-            hipLaunchKernelGGL(rroi_bwd_pairs_relayout_kernel<true>, dim3((unsigned)(pblocks + blocks)),
-                               dim3(256), 0, stream, ws.aff, num_rois, height, width, pooled_width, NB,
-                               batch_size, lines_per_roi, dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs,
-                               pblocks, top_diff, ws.tdT, channels, nchunks, tt, (int)blocks, (int)half,
-                               (int)tiles);
+            if (g_bwd_relayout_aux == 16) RROI_LAUNCH_PR(true, 16, blocks, half, tiles);
+            else if (g_bwd_relayout_aux == 2) RROI_LAUNCH_PR(true, 2, blocks, half, tiles);
+            else RROI_LAUNCH_PR(true, 0, blocks, half, tiles);
         }
+#undef RROI_LAUNCH_PR
         st = launch_status();
         if (st != 1) return st;
         // (3) gather: one thread group per key, no grid-stride

@@ -38,6 +38,18 @@ for name, path, n in (("tiled (gather)", ext.PATH_TILED, 50), ("tiled_atomic (sc
         call(path)
     torch.cuda.synchronize()
     print(f"backward cfg3 {name}: {(time.perf_counter() - t0) / n * 1e6:.1f} us  (workspace {nb / 1e6:.1f} MB)")
+if os.environ.get("RROI_BWD_SWEEP"):
+    for raux in (0, 2, 16):
+        ext._lib.rroi_align_debug_set_bwd_relayout_aux(raux)
+        for _ in range(5):
+            call(ext.PATH_TILED)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            call(ext.PATH_TILED)
+        torch.cuda.synchronize()
+        print(f"backward sweep: relayout store aux={raux}: {(time.perf_counter() - t0) / 50 * 1e6:.1f} us")
+    ext._lib.rroi_align_debug_set_bwd_relayout_aux(2)
 for _ in range(20):
     call(ext.PATH_TILED)
 torch.cuda.synchronize()
