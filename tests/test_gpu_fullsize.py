@@ -85,3 +85,28 @@ def test_cfg4_shard_of_4096(ext, oracle):
         assert hi - lo == 512
         got = ext.forward(F, torch.from_numpy(r[lo:hi]).cuda(), 8, 64, 0.25).cpu().numpy()
         assert np.array_equal(got, oracle.forward_c(f, r[lo:hi], 8, 64, 0.25, threads=oracle.max_threads()))
+
+
+def test_cfg4_single_call_4096_rois(ext):
+    """All 4096 ROIs of configs[3] in ONE call (2 GiB of crops, R*C*PH*PW = 2^29): equals the eight
+    512-ROI shards bit for bit; the backward (2.4 GB workspace, 3.5 M pairs) equals the sum of the
+    shards' backward within the atomic-order tolerance and is linear."""
+    from rroi_align.sharded import shard_bounds
+    f, r = Wk.bench_inputs(R=4096)
+    F, R = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
+    out = ext.forward(F, R, 8, 64, 0.25)
+    assert out.shape == (4096, 256, 8, 64)
+    for rank in range(8):
+        lo, hi = shard_bounds(4096, 8, rank)
+        assert torch.equal(out[lo:hi], ext.forward(F, R[lo:hi].contiguous(), 8, 64, 0.25)), f"shard {rank}"
+    g = torch.empty_like(out).normal_(generator=torch.Generator("cuda").manual_seed(1))
+    gin = ext.backward(g, R, f.shape, 0.25)
+    acc = torch.zeros_like(gin)
+    for rank in range(8):
+        lo, hi = shard_bounds(4096, 8, rank)
+        acc += ext.backward(g[lo:hi].contiguous(), R[lo:hi].contiguous(), f.shape, 0.25)
+    scale = float(acc.abs().max())
+    assert float((gin - acc).abs().max()) <= 1e-4 * scale
+    del out, acc
+    gat = ext.backward(g, R, f.shape, 0.25, path=ext.PATH_TILED_ATOMIC)
+    assert float((gin - gat).abs().max()) <= 1e-4 * scale
