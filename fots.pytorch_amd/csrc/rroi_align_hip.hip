@@ -1738,9 +1738,10 @@ int rroi_align_forward_stages_hip(const float* features, int feature_layout, flo
     return launch_status();
 }
 
-// Exploration knobs used by tools/kbench.hip for the sweeps and ablations quoted in DESIGN.md.
-// They are NOT part of the ABI (not declared in include/rroi_align_hip.h); the defaults are the
-// shipped configuration.
+// Exploration knobs for the sweeps and ablations quoted in DESIGN.md: compiled only with
+// -DRROI_EXPLORE (tools/kbench.hip, `make EXPLORE=1`).  The product library does not export them;
+// the defaults above are the shipped configuration.
+#ifdef RROI_EXPLORE
 int rroi_align_debug_set_store_aux(int v)
 {
     const int old = g_store_aux;
@@ -1783,6 +1784,7 @@ int rroi_align_debug_set_waves_per_cu(int v)
     if (v >= 1 && v <= 64) g_waves_per_cu = v;
     return old;
 }
+#endif  // RROI_EXPLORE
 
 int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batch_size,
                             int num_rois, int height, int width, int channels,

@@ -38,7 +38,7 @@ for name, path, n in (("tiled (gather)", ext.PATH_TILED, 50), ("tiled_atomic (sc
         call(path)
     torch.cuda.synchronize()
     print(f"backward cfg3 {name}: {(time.perf_counter() - t0) / n * 1e6:.1f} us  (workspace {nb / 1e6:.1f} MB)")
-if os.environ.get("RROI_BWD_SWEEP"):
+if os.environ.get("RROI_BWD_SWEEP") and hasattr(ext._lib, "rroi_align_debug_set_bwd_relayout_aux"):  # make EXPLORE=1
     for raux in (0, 2, 16):
         ext._lib.rroi_align_debug_set_bwd_relayout_aux(raux)
         for _ in range(5):
