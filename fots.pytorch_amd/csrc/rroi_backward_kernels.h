@@ -1,0 +1,471 @@
+// rroi_backward_kernels.h -- backward: gather formulation (K3g), atomic scatter (K3), relayout back to NCHW, direct and literal kernels
+// Part of the single translation unit rroi_align_hip.hip (included inside its anonymous
+// namespace, in this order: rroi_device_common.h, rroi_forward_kernels.h,
+// rroi_backward_kernels.h, rroi_callers_kernels.h); not a standalone header.
+#pragma once
+
+// ------------------------------------------------------------------------------------
+// K3g: backward as a GATHER (the default tiled backward).  The scatter of K3 is bound by the
+// fp32 atomic rate (113 M lane-atomics at cfg3 -> 0.65 ms).  The (bin, tap) -> pixel relation
+// does not depend on the channel, so it is inverted ONCE per call:
+//   pairs   count pass + exclusive scan + fill pass: for every map pixel the list of
+//           (bin, weight) that the reference's four atomicAdds (kernel.cu:267-274) send to it
+//           -- 442 K pairs of 8 bytes at cfg3, integer atomics on 25.6 K counters;
+//   relayout top_diff (R, C, PH*PW) -> chunk-major (R, C/32, PH*PW + 1, 32) with the forward's
+//           prologue kernel, so that the 32 channels of one bin are one 128-byte line;
+//   gather  one (sub-)wave per pixel walks its list: a 16-byte load per lane and pair, all
+//           channels of the pixel accumulated in registers, one store.  No float atomics, no
+//           memset of the gradient.
+// Taps of a bin that alias one pixel (dx == 0 / dy == 0) become ONE pair: the reference adds
+// w*g and 0*g separately, which for finite g is w*g and for non-finite g is NaN either way;
+// the pair carries an "add 0*g as well" flag (sign bit of the weight) so that both cases are
+// reproduced.
+// ------------------------------------------------------------------------------------
+// Pixel keys of the lists are TILED: a 128-byte line of counters holds an 8 x 4 pixel block
+// (key = ((b*Ht + y/4)*Wt + x/8)*32 + (y%4)*8 + x%8).  Device-scope atomics are bound by the
+// number of line REQUESTS (measured ~10-13 G/s chip-wide, however many lanes a request carries):
+// the 64 bins of a wave lie along a line segment of the map, which crosses ~3x fewer 8 x 4
+// blocks than 32 x 1 row segments.
+struct KeyLayout {
+    unsigned Wt, Ht;   // blocks per row / per column
+    unsigned keys;     // batch * Ht * Wt * 32
+};
+
+__device__ __forceinline__ unsigned pixel_key(const KeyLayout& L, unsigned b, unsigned y, unsigned x)
+{
+    return (((b * L.Ht + (y >> 2)) * L.Wt + (x >> 3)) << 5) + ((y & 3u) << 3) + (x & 7u);
+}
+
+// The (pixel, weight) pairs of one bin: the taps that pass kernel.cu:267-274, one pair per
+// DISTINCT pixel.  `emit(key, w)`: w carries the "reference also adds 0*g here" flag in its sign.
+template <class Emit>
+__device__ __forceinline__ void bin_pairs(const Affine& A, unsigned ph, unsigned pw, int height, int width,
+                                          int batch_size, const KeyLayout& L, Emit emit)
+{
+    float bcx, bcy;
+    bool active = bin_centre(A, (int)ph, (int)pw, height, width, bcx, bcy);
+    active = active && A.batch >= 0 && A.batch < batch_size;
+    const Taps tp = make_taps(bcx, bcy, active, height, width, 1u);
+    const unsigned f = tp.flags;
+    if (!(f & kActive)) return;
+    float wlt, wrt, wrb, wlb;
+    tap_weights(tp.rx, tp.ry, wlt, wrt, wrb, wlb);
+    const bool dx = f & kDx, dy = f & kDy;
+    // a passing tap has 0 < x, y < W-1, H-1: the coordinates are small non-negative integers
+    const unsigned x0 = (unsigned)f2i_sat(floorf(bcx)), y0 = (unsigned)f2i_sat(floorf(bcy));
+    const unsigned b = (unsigned)A.batch;
+    const float alias = (dx && dy) ? 1.0f : -1.0f;  // not all four taps distinct: some pixel also gets 0*g
+    // an aliased tap has the bounds of the tap it aliases; weights are positive (NaN only when
+    // every bound has failed)
+    if (f & kB00) emit(pixel_key(L, b, y0, x0), wlt * alias);
+    if (dx && (f & kB01)) emit(pixel_key(L, b, y0, x0 + 1u), wrt * alias);
+    if (dy && (f & kB10)) emit(pixel_key(L, b, y0 + 1u, x0), wlb * alias);
+    if (dx && dy && (f & kB11)) emit(pixel_key(L, b, y0 + 1u, x0 + 1u), wrb * alias);
+}
+
+constexpr unsigned kScanBlock = 4096;  // keys per block of the first scan level
+
+// list offset of key i after the two-level scan
+__device__ __forceinline__ unsigned list_offset(const unsigned* __restrict__ off, const unsigned* __restrict__ bsum, unsigned i)
+{
+    return off[i] + bsum[i / kScanBlock];
+}
+
+// FILL == false: cnt[key] += 1 per pair.  FILL == true: cnt counts back down, handing out the
+// slots of the key's segment.
+template <bool FILL>
+__device__ __forceinline__ void pairs_body(unsigned idx, const Affine* __restrict__ aff, int num_rois,
+                                           int height, int width, int pooled_width, int NB, int batch_size,
+                                           unsigned lines_per_roi, FastDiv div_nb, FastDiv div_pw,
+                                           const KeyLayout& L, int* __restrict__ cnt,
+                                           const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
+                                           uint2* __restrict__ pairs)
+{
+    const unsigned n = fdiv(idx, div_nb);
+    if (n >= (unsigned)num_rois) return;
+    const unsigned j = idx - n * (unsigned)NB;
+    const unsigned ph = fdiv(j, div_pw);
+    const unsigned pw = j - ph * (unsigned)pooled_width;
+    const Affine A = aff[n];
+    bin_pairs(A, ph, pw, height, width, batch_size, L, [&](unsigned key, float w) {
+        if (!FILL) {
+            atomicAdd(cnt + key, 1);
+        } else {
+            const int slot = atomicAdd(cnt + key, -1) - 1;
+            // line index of (roi n, bin j) in chunk 0 of the relaid-out top_diff
+            pairs[list_offset(off, bsum, key) + (unsigned)slot] = make_uint2(n * lines_per_roi + j, as_u(w));
+        }
+    });
+}
+
+// One launch, two kinds of blocks: [0, pair_blocks) count (FILL = false) or write (FILL = true)
+// the pair lists -- bound by the atomic request rate -- and the rest relay out tiles
+// [tile_begin, tile_end) of top_diff -- bound by HBM.  They share the chip instead of running
+// one after the other; the host gives each of the two launches half of the tiles.
+template <bool FILL, int SAUX>
+__global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
+    const Affine* __restrict__ aff, int num_rois, int height, int width, int pooled_width, int NB,
+    int batch_size, unsigned lines_per_roi, FastDiv div_nb, FastDiv div_pw, KeyLayout L,
+    int* __restrict__ cnt, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
+    uint2* __restrict__ pairs, int pair_blocks, const float* __restrict__ top_diff,
+    float* __restrict__ tdT, int C, int nchunks, int ptiles, int relayout_blocks, int tile_begin,
+    int tile_end)
+{
+    __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
+    if ((int)blockIdx.x < pair_blocks) {
+        const unsigned total = (unsigned)num_rois * (unsigned)NB;
+        for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += (unsigned)pair_blocks * 256u)
+            pairs_body<FILL>(idx, aff, num_rois, height, width, pooled_width, NB, batch_size, lines_per_roi,
+                             div_nb, div_pw, L, cnt, off, bsum, pairs);
+        return;
+    }
+    relayout_run<SAUX, true>(T, top_diff, tdT, C, NB, pooled_width, pooled_width, div_pw, nchunks, ptiles,
+                          tile_begin + (int)blockIdx.x - pair_blocks, relayout_blocks, tile_end, aff,
+                          batch_size);
+}
+
+// Exclusive scan of cnt[0..N) (N = keys + 1, the last element reads as 0), two levels:
+// level 1: every block scans kScanBlock keys -> off[] (block-local) and its total -> bsum[block];
+// level 2: one block scans the totals in place.  Readers add the two (list_offset).
+__device__ __forceinline__ unsigned block_exclusive_scan_1024(unsigned mine, unsigned* wsum, unsigned& total)
+{
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    unsigned incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d, 64);
+        if (lane >= (unsigned)d) incl += o;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned wbase = 0, tot = 0;
+    for (unsigned k = 0; k < 16; ++k) {
+        const unsigned v = wsum[k];
+        if (k < wv) wbase += v;
+        tot += v;
+    }
+    total = tot;
+    __syncthreads();
+    return wbase + incl - mine;
+}
+
+__global__ __launch_bounds__(1024) void rroi_scan1_kernel(const int* __restrict__ cnt, unsigned* __restrict__ off,
+                                                          unsigned* __restrict__ bsum, unsigned keys)
+{
+    __shared__ unsigned wsum[16];
+    const unsigned i0 = blockIdx.x * kScanBlock + threadIdx.x * 4u;
+    unsigned v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = i0 + e < keys ? (unsigned)cnt[i0 + e] : 0u;
+    unsigned total;
+    unsigned run = block_exclusive_scan_1024(v[0] + v[1] + v[2] + v[3], wsum, total);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (i0 + e <= keys) off[i0 + e] = run;
+        run += v[e];
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void rroi_scan2_kernel(unsigned* __restrict__ bsum, unsigned nblocks)
+{
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (unsigned base = 0; base < nblocks; base += 1024u) {
+        const unsigned i = base + threadIdx.x;
+        const unsigned v = i < nblocks ? bsum[i] : 0u;
+        unsigned total;
+        const unsigned ex = block_exclusive_scan_1024(v, wsum, total);
+        const unsigned carry = carry_s;
+        if (i < nblocks) bsum[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+}
+
+// gather: `sub` = 8 * nchunks_pass lanes serve one pixel (lane -> chunk, channel quad); 64 / sub
+// pixels per wave; one pixel group per thread group, so the hardware's block dispatch balances
+// the (very uneven) list lengths.  The 16-byte loads of eight pairs are in flight together.
+__global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
+    const float* __restrict__ tdT, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
+    const uint2* __restrict__ pairs, float* __restrict__ gcm, int C, int height, int width, int pitch,
+    int nchunks, unsigned lines_per_chunk, unsigned sub_shift, KeyLayout L, FastDiv div_bt, FastDiv div_wt)
+{
+    const unsigned tid = blockIdx.x * 256u + threadIdx.x;
+    const unsigned sub = 1u << sub_shift;              // lanes per pixel (8..64)
+    const unsigned sl = tid & (sub - 1u);              // lane within the pixel's group
+    const unsigned key = tid >> sub_shift;
+    if (key >= L.keys) return;
+    // key -> (b, y, x)
+    const unsigned blk = key >> 5, in = key & 31u;
+    const unsigned b = fdiv(blk, div_bt);              // / (Ht*Wt)
+    const unsigned r = blk - b * (L.Ht * L.Wt);
+    const unsigned by = fdiv(r, div_wt);
+    const unsigned y = by * 4u + (in >> 3), x = (r - by * L.Wt) * 8u + (in & 7u);
+    if (y >= (unsigned)height || x >= (unsigned)width) return;  // padding of the key space
+    const unsigned beg = list_offset(off, bsum, key), end = list_offset(off, bsum, key + 1u);
+    const unsigned quad = sl & 7u;
+    const unsigned slice_px = (unsigned)height * (unsigned)pitch;
+    const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int kDepth = 8;
+    // channel passes of `sub / 8` chunks each (one pass when C <= 256)
+    for (unsigned k0 = 0; k0 < (unsigned)nchunks; k0 += sub >> 3) {
+        const unsigned k = k0 + (sl >> 3);
+        const bool c_ok = k < (unsigned)nchunks && k * kChunk + quad * 4u < (unsigned)C;
+        const float* src = tdT + ((size_t)k * lines_per_chunk) * kChunk + quad * 4u;
+        v4f acc = z4;
+        for (unsigned i = beg; i < end; i += kDepth) {
+            uint2 e[kDepth];
+            v4f g[kDepth];
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) e[d] = i + d < end ? pairs[i + d] : make_uint2(0u, 0u);
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d)
+                g[d] = (c_ok && i + d < end) ? *reinterpret_cast<const v4f*>(src + (size_t)e[d].x * kChunk) : z4;
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) {
+                if (i + d < end) {
+                    // kernel.cu:260-263: v_k = w_k * top_diff, then one add per tap
+                    acc += g[d] * as_f(e[d].y & 0x7fffffffu);
+                    if (e[d].y & 0x80000000u) acc += g[d] * 0.0f;
+                }
+            }
+        }
+        if (c_ok) {
+            float* dst = gcm + (((size_t)b * nchunks + k) * slice_px + (size_t)y * pitch + x) * kChunk + quad * 4u;
+            *reinterpret_cast<v4f*>(dst) = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K3: backward as a SCATTER (RROI_PATH_TILED_ATOMIC; the first tiled backward, kept for
+// comparison and for problems whose pair lists do not fit 32-bit indices): into a zeroed
+// chunk-major gradient (B, C/32, H*Wp, 32) with hardware fp32 atomics, then relayout to NCHW.
+// Same item decomposition as the forward.
+// Measured on MI355X (tools/kbench): an atomic wave instruction that covers 2 full 128-byte
+// lines sustains 325 G lane-atomics/s, one that touches 8 lines at a 16-byte stride only
+// 80 G/s.  So the (bin, tap) contributions of a tile are first COMPACTED into a list (only
+// the taps that pass the reference's bounds, kernel.cu:267-274), and the scatter loop takes
+// two list entries per instruction: lanes 0-31 add the 32 channels of one pixel, lanes 32-63
+// those of another.
+// ------------------------------------------------------------------------------------
+template <bool VEC_LOAD>
+__global__ __launch_bounds__(kWave) void rroi_bwd_tiled_kernel(
+    const float* __restrict__ top_diff, const Affine* __restrict__ aff, float* __restrict__ gcm,
+    int num_rois, int C, int height, int width, int pitch, int pooled_width, int NB, int batch_size,
+    int nchunks, int ntiles, FastDiv div_tiles, FastDiv div_pw)
+{
+    __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride];
+    __shared__ __attribute__((aligned(16))) uint4 P[kTileBins * 4];  // {float offset of the pixel, weight, bin, -}
+
+    const unsigned lane = threadIdx.x;
+    const unsigned k = blockIdx.x % (unsigned)nchunks;
+    const unsigned slot = blockIdx.x / (unsigned)nchunks;
+    const unsigned nslots = gridDim.x / (unsigned)nchunks;
+    const unsigned items = (unsigned)num_rois * (unsigned)ntiles;
+    const unsigned slice_px = (unsigned)height * (unsigned)pitch;
+    const unsigned col = (lane & 15) * 4, row0 = lane >> 4;
+    const unsigned c = lane & 31, half = lane >> 5;   // scatter phase: channel within the chunk, list parity
+    const bool c_ok = k * kChunk + c < (unsigned)C;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    for (unsigned item = slot; item < items; item += nslots) {
+        const unsigned n = fdiv(item, div_tiles);
+        const unsigned t = item - n * (unsigned)ntiles;
+        const Affine A = aff[n];
+        const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
+        unsigned npairs;
+        {
+            const unsigned bin = t * kTileBins + lane;
+            const unsigned ph = fdiv(bin, div_pw);
+            const unsigned pw = bin - ph * (unsigned)pooled_width;
+            float bcx, bcy;
+            // kernel.cu:232-242: the backward reads the centre the forward stored; where the
+            // forward's mask (pw <= roi_pooled_width) was false it stored nothing, the
+            // buffer holds 0, and a (0,0) centre fails every bound of :267-274.  So the
+            // scatter happens exactly where the forward's mask holds.
+            bool active = bin_centre(A, (int)ph, (int)pw, height, width, bcx, bcy);
+            active = active && bin < (unsigned)NB && batch_ok;
+            const Taps tp = make_taps(bcx, bcy, active, height, width, 1u);
+            float wlt, wrt, wrb, wlb;
+            tap_weights(tp.rx, tp.ry, wlt, wrt, wrb, wlb);
+            const unsigned f = tp.flags;
+            // pixel index on the padded row pitch of the chunk-major gradient, as a float offset
+            const int x0 = f2i_sat(floorf(bcx)), y0 = f2i_sat(floorf(bcy));
+            const unsigned o_lt = ((unsigned)y0 * (unsigned)pitch + (unsigned)x0) * kChunk;
+            const unsigned o_rt = o_lt + ((f & kDx) ? (unsigned)kChunk : 0u);
+            const unsigned o_lb = o_lt + ((f & kDy) ? (unsigned)pitch * kChunk : 0u);
+            const unsigned o_rb = o_lb + ((f & kDx) ? (unsigned)kChunk : 0u);
+            // compaction: list order = all lt entries, then rt, rb, lb (kernel.cu:267-274 order)
+            const unsigned long long m0 = __ballot(f & kB00), m1 = __ballot(f & kB01);
+            const unsigned long long m2 = __ballot(f & kB11), m3 = __ballot(f & kB10);
+            const unsigned n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2);
+            npairs = n0 + n1 + n2 + (unsigned)__popcll(m3);
+            if (f & kB00) P[__popcll(m0 & below)] = make_uint4(o_lt, as_u(wlt), lane, 0u);
+            if (f & kB01) P[n0 + __popcll(m1 & below)] = make_uint4(o_rt, as_u(wrt), lane, 0u);
+            if (f & kB11) P[n0 + n1 + __popcll(m2 & below)] = make_uint4(o_rb, as_u(wrb), lane, 0u);
+            if (f & kB10) P[n0 + n1 + n2 + __popcll(m3 & below)] = make_uint4(o_lb, as_u(wlb), lane, 0u);
+        }
+        // stage the [32 ch][64 bin] slice of top_diff
+        {
+            const float* ibase = top_diff + ((size_t)n * C + k * kChunk) * NB + (size_t)t * kTileBins;
+            const unsigned bin0 = t * kTileBins + col;
+#pragma unroll
+            for (int s = 0; s < kChunk / 4; ++s) {
+                const unsigned r = s * 4 + row0;
+                v4f v = {0.f, 0.f, 0.f, 0.f};
+                if (k * kChunk + r < (unsigned)C) {
+                    const float* ip = ibase + (size_t)(r * (unsigned)NB + col);
+                    if (VEC_LOAD) {
+                        if (bin0 < (unsigned)NB) v = *reinterpret_cast<const v4f*>(ip);
+                    } else {
+                        if (bin0 + 0 < (unsigned)NB) v.x = ip[0];
+                        if (bin0 + 1 < (unsigned)NB) v.y = ip[1];
+                        if (bin0 + 2 < (unsigned)NB) v.z = ip[2];
+                        if (bin0 + 3 < (unsigned)NB) v.w = ip[3];
+                    }
+                }
+                *reinterpret_cast<v4f*>(T + r * kTStride + (col ^ ((r >> 3) * 4u))) = v;
+            }
+        }
+        lds_wave_sync();
+
+        // scatter: two list entries per atomic instruction, 32 consecutive floats each
+        float* gp = gcm + ((size_t)(batch_ok ? A.batch : 0) * nchunks + k) * ((size_t)slice_px * kChunk) + c;
+        const float* trow = T + c * kTStride;
+        const unsigned cswz = (c >> 3) * 4u;
+        for (unsigned i = half; i < npairs; i += 2) {
+            const uint4 e = P[i];
+            // kernel.cu:260-263: v_k = w_k * top_diff_of_bin, one fp32 multiply
+            const float contrib = as_f(e.y) * trow[e.z ^ cswz];
+            if (c_ok) unsafeAtomicAdd(gp + e.x, contrib);
+        }
+        lds_wave_sync();
+    }
+}
+
+// chunk-major gradient (B, nchunks, HW, 32) -> NCHW (B, C, HW); inverse of the prologue's tile.
+__global__ __launch_bounds__(256) void rroi_cm_to_nchw_kernel(const float* __restrict__ cm,
+                                                              float* __restrict__ nchw, int C,
+                                                              int HW, int width, int pitch,
+                                                              FastDiv div_w, int nchunks, int ptiles)
+{
+    __shared__ float T[kChunk * (kRelayoutPx + 1)];
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int pt = bid % ptiles;
+    bid /= ptiles;
+    const int k = bid % nchunks;
+    const int b = bid / nchunks;
+    const int lane = tid & 63, w = tid >> 6;
+    const int p0 = pt * kRelayoutPx, c0 = k * kChunk;
+    const float* src = cm + ((size_t)b * nchunks + k) * ((size_t)(HW / width) * pitch * kChunk);
+    const int cq = lane & 7, pl = lane >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = w * 32 + j * 8 + pl;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        const unsigned gp = (unsigned)(p0 + p);
+        const unsigned y = fdiv(gp, div_w);
+        const size_t pix = (size_t)y * pitch + (gp - y * (unsigned)width);
+        if (p0 + p < HW) v = *reinterpret_cast<const v4f*>(src + pix * kChunk + cq * 4);
+        float* tw = T + (cq * 4) * (kRelayoutPx + 1) + p;
+        tw[0] = v.x;
+        tw[kRelayoutPx + 1] = v.y;
+        tw[2 * (kRelayoutPx + 1)] = v.z;
+        tw[3 * (kRelayoutPx + 1)] = v.w;
+    }
+    __syncthreads();
+    float* dst = nchw + ((size_t)b * C + c0) * HW + p0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = w * 8 + i;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int p = hlf * 64 + lane;
+            if (c0 + c < C && p0 + p < HW) dst[(size_t)c * HW + p] = T[c * (kRelayoutPx + 1) + p];
+        }
+    }
+}
+
+// Backward, direct NCHW (small R): thread = (roi, bin), loops a channel slab.
+__global__ __launch_bounds__(256) void rroi_bwd_direct_kernel(
+    const float* __restrict__ top_diff, const float* __restrict__ rois,
+    float* __restrict__ bottom_diff, int num_rois, int C, int height, int width,
+    int pooled_height, int pooled_width, float spatial_scale, int batch_size, int cslab)
+{
+    const int NB = pooled_height * pooled_width;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)num_rois * NB) return;
+    const int n = (int)(gid / NB);
+    const int bin = (int)(gid - (long)n * NB);
+    const int ph = bin / pooled_width, pw = bin - ph * pooled_width;
+    const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+    if (A.batch < 0 || A.batch >= batch_size) return;
+    float bcx, bcy;
+    if (!bin_centre(A, ph, pw, height, width, bcx, bcy)) return;  // see rroi_bwd_tiled_kernel
+    const Taps tp = make_taps(bcx, bcy, true, height, width, 1u);
+    float wlt, wrt, wrb, wlb;
+    tap_weights(tp.rx, tp.ry, wlt, wrt, wrb, wlb);
+    const unsigned f = tp.flags;
+    const unsigned o_lt = tp.o_lt;
+    const unsigned o_rt = o_lt + ((f & kDx) ? 1u : 0u);
+    const unsigned o_lb = o_lt + ((f & kDy) ? (unsigned)width : 0u);
+    const unsigned o_rb = o_lb + ((f & kDx) ? 1u : 0u);
+    const size_t HW = (size_t)height * width;
+    const int c_begin = blockIdx.y * cslab;
+    const int c_end = min(C, c_begin + cslab);
+    float* plane = bottom_diff + ((size_t)A.batch * C + c_begin) * HW;
+    size_t o = ((size_t)n * C + c_begin) * NB + bin;
+    for (int c = c_begin; c < c_end; ++c, plane += HW, o += NB) {
+        const float g = top_diff[o];
+        if (f & kB00) unsafeAtomicAdd(plane + o_lt, wlt * g);
+        if (f & kB01) unsafeAtomicAdd(plane + o_rt, wrt * g);
+        if (f & kB11) unsafeAtomicAdd(plane + o_rb, wrb * g);
+        if (f & kB10) unsafeAtomicAdd(plane + o_lb, wlb * g);
+    }
+}
+
+// Backward of the reference ABI: literal per-element body of kernel.cu:207-277,
+// reading the bin centre of EVERY element from con_idx_x / con_idx_y.
+__global__ __launch_bounds__(256) void rroi_bwd_literal_kernel(
+    const float* __restrict__ top_diff, const float* __restrict__ con_idx_x,
+    const float* __restrict__ con_idx_y, const float* __restrict__ rois,
+    float* __restrict__ bottom_diff, long nthreads, int C, int height, int width,
+    int pooled_height, int pooled_width)
+{
+    for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads;
+         index += (long)blockDim.x * gridDim.x) {
+        long n = index;
+        const int pw = (int)(n % pooled_width);
+        n /= pooled_width;
+        n /= pooled_height;
+        const int c = (int)(n % C);
+        n /= C;
+        const float* roi = rois + n * 6;
+        const int roi_batch_ind = f2i_sat(roi[0]);
+        const float h = roi[3], w = roi[4];
+        const float rpw = ((float)pooled_height * w) / h;
+        if ((float)pw > rpw) continue;
+        const float bcx = con_idx_x[index], bcy = con_idx_y[index];
+        const Taps tp = make_taps(bcx, bcy, true, height, width, 1u);
+        float wlt, wrt, wrb, wlb;
+        tap_weights(tp.rx, tp.ry, wlt, wrt, wrb, wlb);
+        const unsigned f = tp.flags;
+        const unsigned o_lt = tp.o_lt;
+        const unsigned o_rt = o_lt + ((f & kDx) ? 1u : 0u);
+        const unsigned o_lb = o_lt + ((f & kDy) ? (unsigned)width : 0u);
+        const unsigned o_rb = o_lb + ((f & kDx) ? 1u : 0u);
+        float* plane = bottom_diff + ((size_t)roi_batch_ind * C + c) * height * width;
+        const float g = top_diff[index];
+        if (f & kB00) unsafeAtomicAdd(plane + o_lt, wlt * g);
+        if (f & kB01) unsafeAtomicAdd(plane + o_rt, wrt * g);
+        if (f & kB11) unsafeAtomicAdd(plane + o_rb, wrb * g);
+        if (f & kB10) unsafeAtomicAdd(plane + o_lb, wlb * g);
+    }
+}
+

@@ -1,0 +1,549 @@
+// rroi_forward_kernels.h -- forward: prologue relayout (K0), tiled gather (K1), direct small-R kernel (K2)
+// Part of the single translation unit rroi_align_hip.hip (included inside its anonymous
+// namespace, in this order: rroi_device_common.h, rroi_forward_kernels.h,
+// rroi_backward_kernels.h, rroi_callers_kernels.h); not a standalone header.
+#pragma once
+
+// ------------------------------------------------------------------------------------
+// K0: forward prologue, one launch:
+//   blocks [0, relayout_blocks)      NCHW -> chunk-major: a [32 ch] x [128 px] tile goes
+//                                    through LDS; reads are 512 B runs of a channel row,
+//                                    writes are one contiguous 16 KiB run of the slice;
+//   then zero_blocks                 the zero pixel that ends every slice;
+//   then the rest                    per-ROI affine table (R x 32 B).
+// ------------------------------------------------------------------------------------
+constexpr int kRelayoutPx = 128;
+
+// The relayout proper, shared by the forward prologue (feature map) and the backward (top_diff,
+// R "images" of PH x PW "pixels").  MASK: image b is ROI b and pixels (ph, pw) with
+// pw > roi_pooled_width (or every pixel of a ROI with an invalid batch index) are bins the
+// forward masks -- nothing reads them again, so they are neither loaded nor written.
+constexpr int kTP = kRelayoutPx + 4;
+
+template <int AUX, bool MASK>
+__device__ __forceinline__ void relayout_run(float* __restrict__ T, const float* __restrict__ nchw,
+                                               float* __restrict__ cm, int C, int HW, int width, int pitch,
+                                               FastDiv div_w, int nchunks, int ptiles, int first_tile,
+                                               int tile_stride, int relayout_tiles,
+                                               const Affine* __restrict__ mask_aff, int mask_batches)
+{
+    // [32 ch][128 px] tile, 132-float pitch (16-byte aligned rows for the b128 writes); the
+    // pixel index of rows 8m..8m+7 is XORed with 4m so that the transposed ds_read_b32 of
+    // phase 2 (8 channel quads x 4 pixels per 32-lane group) hits 32 different banks.
+    const int tid = threadIdx.x;
+    const size_t zp_index = (size_t)(HW / width) * pitch;  // pixel index of the zero pixel
+    const size_t slice_stride = (zp_index + 1) * kChunk;
+    const int lane = tid & 63, w = tid >> 6;
+    // phase 1 mapping: lane -> 4 consecutive pixels (x4) of channel row (csub); a wave
+    // instruction reads two 512-byte runs.  phase 2 mapping: lane -> (channel quad, pixel).
+    const int x4 = lane & 31, csub = lane >> 5;
+    const int cq = lane & 7, pl = lane >> 3;
+    // rows of 16-byte aligned float4 (p0 is a multiple of 128): needs HW % 4 == 0 and an aligned base
+    const bool vec_ok = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(nchw) & 15) == 0;
+
+    // (MASK) highest live pooled column of image b: pw <= rpw  <=>  pw <= floor(rpw) for integer pw
+    auto live_limit = [&](int b) -> float {
+        const Affine A = mask_aff[b];
+        return (A.batch >= 0 && A.batch < mask_batches) ? A.rpw : -1.0f;
+    };
+
+    v4f r[4];
+    auto load_tile = [&](int tile) {
+        // chunk index fastest: with the grid a multiple of nchunks a block always relays out
+        // the same chunk, i.e. (8 chunks, blocks dealt round-robin to the 8 XCDs) slice k is
+        // written through the L2 of the XCD whose gather blocks will read it
+        const int k = tile % nchunks;
+        const int pt = (tile / nchunks) % ptiles;
+        const int b = tile / (ptiles * nchunks);
+        const int p0 = pt * kRelayoutPx, c0 = k * kChunk;
+        const float* src = nchw + ((size_t)b * C + c0) * HW + p0;
+        const int p = 4 * x4;
+        bool live = true;
+        if (MASK) {
+            // the four pixels of this lane are dead when the first one is (same row), or when the
+            // run starts in a dead tail and ends in the next row's live head: keep it then
+            const unsigned gp = (unsigned)(p0 + p);
+            const unsigned y = fdiv(gp, div_w);
+            const unsigned x = gp - y * (unsigned)width;
+            const float lim = live_limit(b);
+            live = !((float)x > lim) || x + 3u >= (unsigned)width;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = w * 8 + i * 2 + csub;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (c0 + c < C && live) {
+                const float* sp = src + (size_t)c * HW + p;
+                if (vec_ok && p0 + p + 3 < HW) {
+                    v = *reinterpret_cast<const v4f*>(sp);
+                } else {
+                    if (p0 + p + 0 < HW) v.x = sp[0];
+                    if (p0 + p + 1 < HW) v.y = sp[1];
+                    if (p0 + p + 2 < HW) v.z = sp[2];
+                    if (p0 + p + 3 < HW) v.w = sp[3];
+                }
+            }
+            r[i] = v;
+        }
+    };
+    // grid-stride over tiles, software-pipelined: the loads of the next tile are in flight
+    // while the current tile goes through LDS and out to the chunk-major copy
+    int tile = first_tile;
+    if (tile < relayout_tiles) load_tile(tile);
+    while (tile < relayout_tiles) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = w * 8 + i * 2 + csub;
+            *reinterpret_cast<v4f*>(T + c * kTP + ((4 * x4) ^ ((c >> 3) * 4))) = r[i];
+        }
+        __syncthreads();
+        const int cur = tile;
+        tile += tile_stride;
+        if (tile < relayout_tiles) load_tile(tile);
+        {
+            const int k = cur % nchunks;
+            const int pt = (cur / nchunks) % ptiles;
+            const int b = cur / (ptiles * nchunks);
+            const int p0 = pt * kRelayoutPx;
+            float* dst = cm + ((size_t)b * nchunks + k) * slice_stride;
+            const float lim = MASK ? live_limit(b) : 0.0f;
+            // wave w writes pixels 32w..32w+31: per instruction 8 pixels x 128 B = 1 KiB contiguous
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = w * 32 + j * 8 + pl;
+                const float* tr = T + (cq * 4) * kTP + (p ^ ((cq >> 1) * 4));
+                v4f v = {tr[0], tr[kTP], tr[2 * kTP], tr[3 * kTP]};
+                const unsigned gp = (unsigned)(p0 + p);
+                const unsigned y = fdiv(gp, div_w);
+                const unsigned x = gp - y * (unsigned)width;
+                const size_t pix = (size_t)y * pitch + x;
+                if (p0 + p < HW && !(MASK && (float)x > lim)) {
+                    if (AUX == 0) {
+                        *reinterpret_cast<v4f*>(dst + pix * kChunk + cq * 4) = v;
+                    } else {
+                        const __amdgpu_buffer_rsrc_t ws = make_rsrc(dst, (unsigned)(slice_stride * 4));
+                        buf_store<AUX>(ws, (unsigned)((pix * kChunk + cq * 4) * 4), v);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int AUX>
+__global__ __launch_bounds__(256) void rroi_prologue_kernel(
+    const float* __restrict__ nchw, float* __restrict__ cm, int C, int HW, int width, int pitch,
+    FastDiv div_w, int nchunks, int ptiles, int relayout_blocks, int relayout_tiles, int zero_blocks,
+    int batch_size, const float* __restrict__ rois, int num_rois, int pooled_height,
+    float spatial_scale, Affine* __restrict__ aff)
+{
+    __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= relayout_blocks + zero_blocks) {
+        const int n = ((int)blockIdx.x - relayout_blocks - zero_blocks) * 256 + tid;
+        if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+        return;
+    }
+    if ((int)blockIdx.x >= relayout_blocks) {
+        const size_t zp_index = (size_t)(HW / width) * pitch;  // pixel index of the zero pixel
+        const size_t slice_stride = (zp_index + 1) * kChunk;
+        const int i = ((int)blockIdx.x - relayout_blocks) * 256 + tid;  // (slice, channel-in-chunk)
+        if (i < batch_size * nchunks * kChunk)
+            cm[(size_t)(i / kChunk) * slice_stride + zp_index * kChunk + (i % kChunk)] = 0.0f;
+        return;
+    }
+    relayout_run<AUX, false>(T, nchw, cm, C, HW, width, pitch, div_w, nchunks, ptiles, (int)blockIdx.x,
+                               relayout_blocks, relayout_tiles, nullptr, 0);
+}
+
+__global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois, int pooled_height,
+                                   float spatial_scale, Affine* __restrict__ aff)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+}
+
+// ------------------------------------------------------------------------------------
+// K1: the hot kernel.  One wave per block; block -> channel chunk k = blockIdx %
+// nchunks (XCD affinity) and a grid-stride loop over (roi, 64-bin tile) items.
+//   phase A  lane = bin: geometry -> one 16-byte tap record per bin in LDS, sorted by
+//            class (bins with <= 2 distinct taps, bins with 4); an invalid tap is the
+//            out-of-range offset kOOB, which the buffer descriptor turns into 0.0.
+//   phase B  lane = (bin b of 8, channel quad q of 8): 2 or 4 buffer loads per group
+//            of 8 bins, blend, transpose through LDS; depth-2 software pipeline.
+//   phase C  the [32 ch][64 bin] tile leaves LDS as 16-byte streaming stores, 256 B
+//            per row.
+// The three phases of consecutive items are interleaved around the store burst, see the
+// loop at the end.
+// ------------------------------------------------------------------------------------
+template <bool VEC_STORE, int AUX>
+__global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
+    const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
+    int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
+    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg)
+{
+    // A tile's bins are processed in CLASS-SORTED groups of 8, because the texture addresser
+    // charges 16 cycles for every dwordx4 wave instruction whatever the number of lanes that
+    // really fetch (measured: 16.1 / 15.6 / 15.2 clk with 0 / 50 / 87 % of the lanes out of
+    // range).  Issuing all 4 taps for all 64 bins costs 32 load instructions per tile although
+    // only ~1.3 taps per bin are distinct pixels.  Sorted:
+    //   LO  bins with at most two distinct taps (lt, and rt OR lb): 2 loads per group;
+    //   HI  bins with four distinct taps (dx and dy):                4 loads per group;
+    //   masked bins (pw > roi_pooled_width) are in no group -- phase C writes their zeros.
+    // Typical tile: 5 LO + 2 HI groups = 18 load instructions instead of 32.
+    constexpr int kMaxGroups = kIters + 2;  // two classes, each padded to a multiple of 8
+    constexpr unsigned kPadPos = kTileBins;  // "bin position" of a padding record
+    // T: rows 0..31 are the tile; the tail absorbs the writes of padding records (4 rows at the
+    // tile's pitch, 32 columns).  LDS is granted in 1280-byte granules on gfx950: the block must
+    // stay <= 12800 B for 12 waves per CU.
+    __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride + 3 * kTStride + 32];
+    // tap records of two items: item i+1 is sampled out of one set while the other is being
+    // built for item i+2
+    constexpr int kRecs = kMaxGroups * kBinsPerIter;
+    __shared__ __attribute__((aligned(16))) uint4 Gbuf[2 * kRecs];
+    __shared__ unsigned char HPbuf[2 * kRecs];
+
+    const unsigned lane = threadIdx.x;
+    const unsigned k = blockIdx.x % (unsigned)nchunks;
+    const unsigned slot = blockIdx.x / (unsigned)nchunks;
+    const unsigned nslots = gridDim.x / (unsigned)nchunks;
+    const unsigned items = (unsigned)num_rois * (unsigned)ntiles;
+    const unsigned px_bytes = lay.px_bytes;
+    const unsigned row_bytes = lay.row_bytes;
+
+    // lane = q + 8*b: the 8 lanes that fetch the 8 channel quads of ONE pixel (one 128-byte
+    // line) are consecutive, so the texture addresser merges them into two 64-byte
+    // accesses.  (With the quads strided over the wave every lane costs its own access:
+    // measured 43 vs 16 TCP accesses per load instruction.)
+    const unsigned q = lane & (kQuads - 1), b = lane >> 3;
+    // a channel quad wholly beyond C never loads (its rows are not stored either)
+    const unsigned q_bytes = ((dbg & 2) || k * kChunk + q * 4 >= (unsigned)C) ? kOOB : q * 16u;
+    // LDS tile: row r = channel, 68-dword pitch; the column of rows 8m..8m+7 is XORed with
+    // 4*m so that the 32 lanes of a store group (8 quads x 4 bins) spread over the banks
+    // while rows stay 16-byte aligned for the ds_read_b128 of phase C.
+    const unsigned wswz = (q >> 1) * 4u;  // rows 4q..4q+3 -> m = q >> 1
+    const unsigned col = (lane & 15) * 4, row0 = lane >> 4;
+    const unsigned chans_here = min((unsigned)kChunk, (unsigned)C - k * kChunk);  // rows of this chunk < C
+    const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+
+    unsigned g_lo = 0, g_hi = 0;          // groups of the current item (wave-uniform)
+    unsigned long long act_mask = 0;      // bins of the current item that are in a group
+
+    // phase A of one item: lane = bin, geometry -> sorted 16-byte tap records in LDS:
+    //   LO: {off_lt, off_2nd, w_lt, bin position}      (w_2nd = 1 - w_lt, see blend_lo)
+    //   HI: {off_lt, off_rt, off_lb, off_rb}, bin position in HP[]   (all four weights are 1/4)
+    // Offsets are byte offsets into the slice; kOOB reads as 0.0, which is what
+    // kernel.cu:116-126 substitutes for a tap outside the map.
+    auto geometry = [&](const Affine& A, unsigned t, unsigned p, unsigned& n_lo_groups,
+                        unsigned& n_hi_groups, unsigned long long& amask) {
+        uint4* const G = Gbuf + p * kRecs;
+        unsigned char* const HP = HPbuf + p * kRecs;
+        const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
+        const unsigned bin = t * kTileBins + lane;
+        const unsigned ph = fdiv(bin, div_pw);
+        const unsigned pw = bin - ph * (unsigned)pooled_width;
+        float bcx, bcy;
+        bool active = bin_centre(A, (int)ph, (int)pw, height, width, bcx, bcy);
+        active = active && bin < (unsigned)NB && batch_ok;
+        const float fx = floorf(bcx), fy = floorf(bcy);
+        const int x0 = f2i_sat(fx), x1 = f2i_sat(ceilf(bcx));
+        const int y0 = f2i_sat(fy), y1 = f2i_sat(ceilf(bcy));
+        const bool x0ok = x0 > 0 && x0 < width, x1ok = x1 > 0 && x1 < width;
+        const bool y0ok = y0 > 0 && y0 < height, y1ok = y1 > 0 && y1 < height;
+        const bool dx = active && x1 != x0, dy = active && y1 != y0;
+        // kernel.cu:116-126 validity; a tap that aliases lt (dx == 0 / dy == 0) is not loaded
+        const unsigned o00 = (unsigned)y0 * row_bytes + (unsigned)x0 * px_bytes;
+        const unsigned o_lt = (active && y0ok && x0ok) ? o00 : kOOB;
+        const unsigned o_rt = (dx && y0ok && x1ok) ? o00 + px_bytes : kOOB;
+        const unsigned o_lb = (dy && y1ok && x0ok) ? o00 + row_bytes : kOOB;
+        const unsigned o_rb = (dx && dy && y1ok && x1ok) ? o00 + row_bytes + px_bytes : kOOB;
+        const bool hi = dx && dy, lo = active && !hi;
+        const unsigned long long m_lo = __ballot(lo), m_hi = __ballot(hi);
+        const unsigned n_lo = __popcll(m_lo), n_hi = __popcll(m_hi);
+        // at least one LO group (all padding if need be): its loads are issued unconditionally,
+        // one item ahead, before the previous item's stores
+        n_lo_groups = n_lo ? (n_lo + kBinsPerIter - 1) / kBinsPerIter : 1u;
+        n_hi_groups = (n_hi + kBinsPerIter - 1) / kBinsPerIter;
+        amask = m_lo | m_hi;
+        const unsigned hi_base = n_lo_groups * kBinsPerIter;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned idx = lo ? __popcll(m_lo & below) : hi_base + __popcll(m_hi & below);
+        const float rx = bcx - fx, ry = bcy - fy;
+        const float wlt = (1.0f - rx) * (1.0f - ry);  // kernel.cu:131
+        if (active) {
+            // LO: the one other distinct tap is rt (dx) or lb (dy); neither -> kOOB, weight 0
+            G[idx] = make_uint4(o_lt, dx ? o_rt : o_lb, hi ? o_lb : as_u(wlt), hi ? o_rb : lane);
+            HP[idx] = (unsigned char)lane;
+        }
+        // pad both classes to whole groups with records that load nothing and store nowhere
+        const unsigned pad_lo = hi_base - n_lo, pad_hi = n_hi_groups * kBinsPerIter - n_hi;
+        if (lane < pad_lo + pad_hi) {
+            const bool plo = lane < pad_lo;
+            const unsigned pidx = plo ? n_lo + lane : hi_base + n_hi + (lane - pad_lo);
+            G[pidx] = make_uint4(kOOB, kOOB, plo ? 0u : kOOB, plo ? kPadPos : kOOB);
+            HP[pidx] = (unsigned char)kPadPos;
+        }
+    };
+    uint4 ra[2];
+    unsigned hpos[2];
+    v4f lt[2], rt[2], lb[2], rbv[2];
+    auto fetch_lo = [&](unsigned p, unsigned grp, int s) { ra[s] = Gbuf[p * kRecs + grp * kBinsPerIter + b]; };
+    auto fetch_hi = [&](unsigned p, unsigned grp, int s) {
+        ra[s] = Gbuf[p * kRecs + grp * kBinsPerIter + b];
+        hpos[s] = HPbuf[p * kRecs + grp * kBinsPerIter + b];
+    };
+    auto issue_lo = [&](__amdgpu_buffer_rsrc_t rs, int s) {
+        // kOOB + q_bytes (or anything + kOOB) stays out of range: no wrap below 2^32
+        lt[s] = buf_load(rs, ra[s].x + q_bytes);
+        rt[s] = buf_load(rs, ra[s].y + q_bytes);  // the bin's one other distinct tap, if any
+    };
+    auto issue_hi = [&](__amdgpu_buffer_rsrc_t rs, int s) {
+        lt[s] = buf_load(rs, ra[s].x + q_bytes);
+        rt[s] = buf_load(rs, ra[s].y + q_bytes);
+        lb[s] = buf_load(rs, ra[s].z + q_bytes);
+        rbv[s] = buf_load(rs, ra[s].w + q_bytes);
+    };
+    float* const t_row = T + (q * 4) * kTStride;
+    float* const t_pad = T + kChunk * kTStride + (lane & 31u);
+    auto put = [&](unsigned pos, v4f v) {
+        float* tw = pos < (unsigned)kTileBins ? t_row + (pos ^ wswz) : t_pad;
+        tw[0 * kTStride] = v.x;
+        tw[1 * kTStride] = v.y;
+        tw[2 * kTStride] = v.z;
+        tw[3 * kTStride] = v.w;
+    };
+    auto blend_lo = [&](int s) {
+        // At most two distinct pixels p (= lt) and p2, with weights w and 1 - w
+        // (w = 1: p alone; w = 1/2: p and its right OR lower neighbour; kernel.cu:131-134 with
+        // rx, ry in {0, 1/2}).  The reference adds all four terms (:138-141); the two that
+        // re-read p or p2 carry weight exactly 0.  So
+        //   taps finite      -> those terms add +-0 and the sum is  (0 + p*w) + p2*(1-w);
+        //   a tap non-finite -> the reference's 0 * tap is NaN, and so is its sum.
+        // The two-term sum is finite exactly when both taps are (both weights are non-zero and
+        // at most 1), so adding  v - v  (0, or NaN when v is not finite) reproduces the
+        // reference bit for bit in both cases.  A NaN weight (centre at infinity) gives NaN
+        // either way.
+        const float w = as_f(ra[s].z), w2 = 1.0f - w;
+        v4f v = z4;
+        v += lt[s] * w;
+        v += rt[s] * w2;
+        v += v - v;
+        put(ra[s].w, v);
+    };
+    auto blend_hi = [&](int s) {
+        // four distinct pixels: dx and dy, so rx = ry = 1/2 and every weight is 1/4
+        v4f v = z4;  // kernel.cu:136-141, four channels at a time
+        v += lt[s] * 0.25f;
+        v += rt[s] * 0.25f;
+        v += rbv[s] * 0.25f;
+        v += lb[s] * 0.25f;
+        put(hpos[s], v);
+    };
+    // An empty asm that "rewrites" the current group's taps: placed right after the next
+    // group's loads are issued, it pins the first use of the current taps (and with it the
+    // s_waitcnt) BEHIND that issue.  Without it the compiler hoists the first multiplies of the
+    // blend above the "more groups?" branch and waits before anything new is in flight.
+    auto pin_lo = [&](int s) { asm volatile("" : "+v"(lt[s]), "+v"(rt[s])); };
+    auto pin_hi = [&](int s) { asm volatile("" : "+v"(lt[s]), "+v"(rt[s]), "+v"(lb[s]), "+v"(rbv[s])); };
+
+    // phase C of one item: [rows < C] x [64 bins] -> 256-byte row segments
+    // `live` = false turns every store into an out-of-range one (dropped by the descriptor
+    // check) instead of branching around them: the instruction stream of the loop must be the
+    // same on every path, or the compiler's s_waitcnt counts -- which take the most
+    // conservative value where paths merge -- degrade to vmcnt(0) and every blend waits for
+    // the store acknowledgements.  (Also the ablation knob: dbg & 1 drops the output stores.)
+    auto store_tile = [&](unsigned n, unsigned t, unsigned long long cur_mask, bool live) {
+        live = live && !(dbg & 1);
+        // descriptor over this (roi, chunk) block of the output: rows >= C fall out of range
+        float* obase = out + ((size_t)n * C + k * kChunk) * NB;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, chans_here * (unsigned)NB * 4u);
+        const unsigned bin0 = t * kTileBins + col;
+        // bins that were in no group (masked by pw > roi_pooled_width) are zero
+        const unsigned nib = (unsigned)(cur_mask >> col) & 15u;
+        const bool a0 = nib & 1u, a1 = nib & 2u, a2 = nib & 4u, a3 = nib & 8u;
+        // two halves of 4 row groups: 16 instead of 32 registers live across the LDS reads
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+            v4f v[kChunk / 8];
+#pragma unroll
+            for (int s4 = 0; s4 < kChunk / 8; ++s4) {
+                const unsigned r = (hs * (kChunk / 8) + s4) * 4 + row0;
+                v[s4] = *reinterpret_cast<const v4f*>(T + r * kTStride + (col ^ ((r >> 3) * 4u)));
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < kChunk / 8; ++s4) {
+                const unsigned r = (hs * (kChunk / 8) + s4) * 4 + row0;
+                const unsigned off = (r * (unsigned)NB + bin0) * 4u;
+                const v4f o = {a0 ? v[s4].x : 0.f, a1 ? v[s4].y : 0.f, a2 ? v[s4].z : 0.f, a3 ? v[s4].w : 0.f};
+                if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
+                    // AUX == 2 (the shipped policy): the first of the tile's eight stores goes out
+                    // write-through (sc0 sc1), the other seven streaming (nt) -- see buf_store
+                    if (AUX == 2 && hs == 0 && s4 == 0)
+                        buf_store<kMinorAux>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);
+                    else
+                    buf_store<AUX>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);
+                } else {
+                    buf_store1<AUX>(ws, (live && bin0 + 0 < (unsigned)NB) ? off + 0 : kOOB, o.x);
+                    buf_store1<AUX>(ws, (live && bin0 + 1 < (unsigned)NB) ? off + 4 : kOOB, o.y);
+                    buf_store1<AUX>(ws, (live && bin0 + 2 < (unsigned)NB) ? off + 8 : kOOB, o.z);
+                    buf_store1<AUX>(ws, (live && bin0 + 3 < (unsigned)NB) ? off + 12 : kOOB, o.w);
+                }
+            }
+        }
+    };
+
+    // Software pipeline over the items of this wave.  gfx950 counts loads and stores with ONE
+    // in-order counter, so a load issued after a tile's stores cannot be consumed before those
+    // stores are acknowledged by the memory system (microseconds, with 256 MiB streaming out).
+    // Per iteration, with the tile of item i-1 complete in T and the records of item i in set p:
+    //   1. the first loads of item i are issued (they are AHEAD of the stores in the counter);
+    //   2. tile i-1 leaves: LDS -> registers -> 8 x 1 KiB streaming stores;
+    //   3. geometry of item i+1 -> record set p^1: ~250 instructions that depend on no memory
+    //      access, run while the stores drain;
+    //   4. phase B of item i -> T (its later groups do wait for the store acknowledgements).
+    unsigned cur = slot;
+    if (cur >= items) return;
+    unsigned n = fdiv(cur, div_tiles);
+    unsigned t = cur - n * (unsigned)ntiles;
+    unsigned p = 0;
+    unsigned n_prev = 0, t_prev = 0;
+    unsigned long long mask_prev = 0;
+    bool have_prev = false;
+    unsigned g_lo_next = 0, g_hi_next = 0;
+    unsigned long long mask_next = 0;
+    {
+        const Affine A = aff[n];
+        geometry(A, t, 0, g_lo, g_hi, act_mask);
+    }
+    int batch = aff[n].batch;
+    lds_wave_sync();
+
+    for (;;) {
+        const unsigned nxt = cur + nslots;
+        const bool has_next = nxt < items;
+        const unsigned n_next = has_next ? fdiv(nxt, div_tiles) : n;
+        const unsigned t_next = nxt - n_next * (unsigned)ntiles;
+        const Affine A_next = aff[n_next];  // scalar loads, in flight during steps 1-2
+
+        const bool batch_ok = batch >= 0 && batch < batch_size;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(
+            map + (size_t)(batch_ok ? batch : 0) * lay.img_stride + (size_t)k * lay.chunk_stride, lay.slice_bytes);
+        fetch_lo(p, 0, 0);
+        issue_lo(rs, 0);  // LO group 0 (there always is one)
+        store_tile(n_prev, t_prev, mask_prev, have_prev);
+        lds_wave_sync();  // T has been read: free for this item's blends
+        if (has_next) geometry(A_next, t_next, p ^ 1u, g_lo_next, g_hi_next, mask_next);
+
+        // ---- phase B: LO groups (group 0 is already in flight), then HI groups; the loads of
+        // group g+1 are issued before group g is blended.  The loops are unrolled with an early
+        // exit, and the two exit paths end in different (empty) asm statements so that the
+        // compiler cannot merge their tails: each blend then has ONE predecessor and its
+        // s_waitcnt knows exactly how many younger loads are in flight.
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int s = it & 1;
+            if ((unsigned)(it + 1) < g_lo) {
+                fetch_lo(p, it + 1, s ^ 1);
+                issue_lo(rs, s ^ 1);
+                pin_lo(s);
+                blend_lo(s);
+                asm volatile("; lo: more groups follow");
+            } else {
+                blend_lo(s);
+                asm volatile("; lo: last group");
+                break;
+            }
+        }
+        if (g_hi > 0) {
+            fetch_hi(p, g_lo, 0);
+            issue_hi(rs, 0);
+#pragma unroll
+            for (int it = 0; it < kIters; ++it) {
+                const int s = it & 1;
+                if ((unsigned)(it + 1) < g_hi) {
+                    fetch_hi(p, g_lo + it + 1, s ^ 1);
+                    issue_hi(rs, s ^ 1);
+                    pin_hi(s);
+                    blend_hi(s);
+                    asm volatile("; hi: more groups follow");
+                } else {
+                    blend_hi(s);
+                    asm volatile("; hi: last group");
+                    break;
+                }
+            }
+        }
+        lds_wave_sync();  // T complete; record set p^1 complete
+        if (!has_next) {
+            store_tile(n, t, act_mask, true);
+            break;
+        }
+        n_prev = n;
+        t_prev = t;
+        mask_prev = act_mask;
+        have_prev = true;
+        cur = nxt;
+        n = n_next;
+        t = t_next;
+        batch = A_next.batch;
+        g_lo = g_lo_next;
+        g_hi = g_hi_next;
+        act_mask = mask_next;
+        p ^= 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K2: direct NCHW forward, no workspace: thread = (roi, bin), loops a channel slab.
+// Used for small R (where relaying out the whole map would dominate) and by the
+// reference-ABI launcher; optionally writes the reference's con_idx_x / con_idx_y.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
+    const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
+    float* __restrict__ idx_x, float* __restrict__ idx_y, int num_rois, int C, int height,
+    int width, int pooled_height, int pooled_width, float spatial_scale, int batch_size,
+    int cslab)
+{
+    const int NB = pooled_height * pooled_width;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)num_rois * NB) return;
+    const int n = (int)(gid / NB);
+    const int bin = (int)(gid - (long)n * NB);
+    const int ph = bin / pooled_width, pw = bin - ph * pooled_width;
+
+    const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+    float bcx, bcy;
+    const bool in_rroi = bin_centre(A, ph, pw, height, width, bcx, bcy);
+    // batch_size < 0: unknown (reference ABI) -> trust the index like the reference does
+    const bool batch_ok = batch_size < 0 || (A.batch >= 0 && A.batch < batch_size);
+    const bool active = in_rroi && batch_ok;
+    const Taps tp = make_taps(bcx, bcy, active, height, width, 1u);
+    float wlt, wrt, wrb, wlb;
+    tap_weights(tp.rx, tp.ry, wlt, wrt, wrb, wlb);
+    const unsigned f = tp.flags;
+    const unsigned o_lt = tp.o_lt;
+    const unsigned o_rt = o_lt + ((f & kDx) ? 1u : 0u);
+    const unsigned o_lb = o_lt + ((f & kDy) ? (unsigned)width : 0u);
+    const unsigned o_rb = o_lb + ((f & kDx) ? 1u : 0u);
+
+    const size_t HW = (size_t)height * width;
+    const int c_begin = blockIdx.y * cslab;
+    const int c_end = min(C, c_begin + cslab);
+    const float* plane = feat + ((size_t)(batch_ok ? A.batch : 0) * C + c_begin) * HW;
+    size_t o = ((size_t)n * C + c_begin) * NB + bin;
+    for (int c = c_begin; c < c_end; ++c, plane += HW, o += NB) {
+        float v = 0.0f;
+        if (active) {
+            const float lt = (f & kV00) ? plane[o_lt] : 0.0f;
+            const float rt = (f & kV01) ? plane[o_rt] : 0.0f;
+            const float lb = (f & kV10) ? plane[o_lb] : 0.0f;
+            const float rb = (f & kV11) ? plane[o_rb] : 0.0f;
+            v = blend1(lt, rt, rb, lb, wlt, wrt, wrb, wlb);
+        }
+        out[o] = v;
+        if (idx_x) idx_x[o] = active ? bcx : 0.0f;
+        if (idx_y) idx_y[o] = active ? bcy : 0.0f;
+    }
+}
+
