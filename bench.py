@@ -177,6 +177,30 @@ def main():
     launch(ext.STAGE_ALL)  # leave the real result in `out`
     torch.cuda.synchronize()
 
+    # configs[2] on the side (not part of `value`): backward w.r.t. the features, same shapes
+    bwd_ms = None
+    if world == 1:
+        gout = torch.randn_like(out)
+        nb_b = ext._lib.rroi_align_backward_workspace_bytes(1, c["C"], c["H"], c["W"], R, c["PH"], c["PW"])
+        ws_b = torch.empty(nb_b, dtype=torch.uint8, device=dev)
+        gin = torch.empty((1, c["C"], c["H"], c["W"]), dtype=torch.float32, device=dev)
+
+        def bwd():
+            st = ext._lib.rroi_align_backward_hip(gout.data_ptr(), c["scale"], 1, R, c["H"], c["W"], c["C"],
+                                                  c["PH"], c["PW"], rois.data_ptr(), gin.data_ptr(),
+                                                  ws_b.data_ptr(), nb_b, ext.PATH_TILED, stream)
+            if st != 1:
+                raise RuntimeError(f"rroi_align_backward_hip -> {st}")
+        for _ in range(10):
+            bwd()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            bwd()
+        torch.cuda.synchronize()
+        bwd_ms = (time.perf_counter() - t0) / 50 * 1e3
+        del gout, ws_b, gin
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -225,6 +249,10 @@ def main():
                                     "GB/s": round(out.numel() * 4 / (fill_ms * 1e-3) / 1e9, 1),
                                     "frac_of_it": round(achieved / (out.numel() * 4 / (fill_ms * 1e-3) / 1e9), 4)}},
         "cpu_baseline": cpu,
+        "backward": None if bwd_ms is None else {
+            "what": "configs[2]: grad w.r.t. the features, same shapes, rroi_align_backward_hip (gather path), "
+                    "wall time per call over 50 calls; not part of `value`",
+            "ms_per_call": round(bwd_ms, 5)},
     }
     print(json.dumps(line))
     if dist is not None:
