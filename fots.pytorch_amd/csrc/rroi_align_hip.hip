@@ -215,14 +215,25 @@ BwdWorkspace carve_bwd(void* ws, int batch_size, int channels, int height, int w
     return w;
 }
 
-// AUTO: the tiled path pays one pass over the whole map (read + write B*C*H*W);
-// the direct path pays ~4 uncoalesced taps per output.  Tiled wins once the
-// output is a few times larger than the map.
-bool pick_tiled(int batch_size, int channels, int height, int width, int num_rois, int NB)
+// AUTO.  The tiled paths have a fixed cost (forward: two launches, ~16 us wall; backward: eight,
+// ~35 us) plus a term in the size of the whole map (relayout; the backward also visits every
+// pixel); the direct paths cost per output element, the backward's with four float atomics.
+// Measured crossovers (tools/crossover.py, MI355X, wall time per call):
+//   forward   C=256 160x160 8x64:  R=16 direct 20 / tiled 17.5,  R=32 40 / 17.5,  R=512 579 / 58
+//             C=64 176x320 11x96:  R=32 direct 13 / tiled 16,    R=64 21 / 17,    R=512 155 / 37
+//   backward  C=256:  R=4 direct 59 / tiled 43,   R=32 448 / 50,   R=512 7145 / 195
+//             C=64:   R=4 direct 15 / tiled 34,   R=16 105 / 39,   R=512 1745 / 113
+bool pick_tiled_fwd(int batch_size, int channels, int height, int width, int num_rois, int NB)
 {
     const double out_elems = (double)num_rois * channels * NB;
     const double map_elems = (double)batch_size * channels * height * width;
-    return out_elems >= 2.0 * map_elems;
+    return out_elems >= 3.0e6 && out_elems >= map_elems / 4;
+}
+bool pick_tiled_bwd(int batch_size, int channels, int height, int width, int num_rois, int NB)
+{
+    const double out_elems = (double)num_rois * channels * NB;
+    const double map_elems = (double)batch_size * channels * height * width;
+    return out_elems >= 0.5e6 && out_elems >= map_elems / 16;
 }
 
 int g_store_aux = 2;   // cache policy of the output stores (see buf_store); 16 / 0 for exploration
@@ -288,7 +299,7 @@ int rroi_align_forward_stages_hip(const float* features, int feature_layout, flo
     bool tiled;
     if (path == RROI_PATH_AUTO)
         tiled = feature_layout == RROI_LAYOUT_NHWC ||
-                pick_tiled(batch_size, channels, height, width, num_rois, NB);
+                pick_tiled_fwd(batch_size, channels, height, width, num_rois, NB);
     else
         tiled = path == RROI_PATH_TILED;
     if (!tiled && feature_layout != RROI_LAYOUT_NCHW) return 0;  // direct path reads NCHW only
@@ -440,7 +451,7 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
     if (!top_diff || !rois) return 0;
 
     const bool tiled = path == RROI_PATH_AUTO
-                           ? pick_tiled(batch_size, channels, height, width, num_rois, NB)
+                           ? pick_tiled_bwd(batch_size, channels, height, width, num_rois, NB)
                            : path != RROI_PATH_DIRECT;
     if (!tiled) {
         hipError_t e = hipMemsetAsync(bottom_diff, 0, in_bytes, stream);
