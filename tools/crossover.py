@@ -13,9 +13,9 @@ def T(fn, n=50):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 
-for C, H, W, ph, pw in ((256, 160, 160, 8, 64), (64, 176, 320, 11, 96)):
+for C, H, W, ph, pw, B in ((256, 160, 160, 8, 64, 1), (64, 176, 320, 11, 96, 1), (64, 160, 160, 11, 100, 8)):
     for R in (4, 16, 32, 64, 128, 256, 512):
-        f, r = Wk.bench_inputs(R=R, C=C, H=H, W=W, img=4 * W, seed=R)
+        f, r = Wk.bench_inputs(R=R, C=C, H=H, W=W, img=4 * W, seed=R, batch=B)
         F, Rr = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
         g = torch.randn(R, C, ph, pw, device="cuda")
         fd = T(lambda: ext.forward(F, Rr, ph, pw, 0.25, path=ext.PATH_DIRECT))
@@ -24,5 +24,5 @@ for C, H, W, ph, pw in ((256, 160, 160, 8, 64), (64, 176, 320, 11, 96)):
         bd = T(lambda: ext.backward(g, Rr, f.shape, 0.25, path=ext.PATH_DIRECT), 20)
         bt = T(lambda: ext.backward(g, Rr, f.shape, 0.25, path=ext.PATH_TILED), 20)
         ba = T(lambda: ext.backward(g, Rr, f.shape, 0.25), 20)
-        ratio = R * C * ph * pw / (C * H * W)
-        print(f"C={C} {H}x{W} {ph}x{pw} R={R:4d} out/map={ratio:6.2f}  fwd direct {fd:7.1f} tiled {ft:7.1f} auto {fa:7.1f} | bwd direct {bd:8.1f} tiled {bt:7.1f} auto {ba:8.1f}")
+        ratio = R * C * ph * pw / (B * C * H * W)
+        print(f"B={B} C={C} {H}x{W} {ph}x{pw} R={R:4d} out/map={ratio:6.2f}  fwd direct {fd:7.1f} tiled {ft:7.1f} auto {fa:7.1f} | bwd direct {bd:8.1f} tiled {bt:7.1f} auto {ba:8.1f}")
