@@ -177,6 +177,32 @@ def main():
     launch(ext.STAGE_ALL)  # leave the real result in `out`
     torch.cuda.synchronize()
 
+    # on the side (not part of `value`): the same call when the producer hands over channels-last
+    # features -- consumed in place, no relayout
+    nhwc_ms = None
+    if world == 1:
+        feats_cl = feats.contiguous(memory_format=torch.channels_last)  # storage (B, H, W, C)
+        nb_cl = ext._lib.rroi_align_forward_workspace_bytes(1, c["C"], c["H"], c["W"], R, ext.LAYOUT_NHWC)
+        ws_cl = torch.empty(max(nb_cl, 1), dtype=torch.uint8, device=dev)
+
+        def fwd_cl():
+            st = ext._lib.rroi_align_forward_hip(feats_cl.data_ptr(), ext.LAYOUT_NHWC, c["scale"], 1, R, c["H"],
+                                                 c["W"], c["C"], c["PH"], c["PW"], rois.data_ptr(),
+                                                 out.data_ptr(), ws_cl.data_ptr(), nb_cl, ext.PATH_TILED, stream)
+            if st != 1:
+                raise RuntimeError(f"rroi_align_forward_hip(NHWC) -> {st}")
+        for _ in range(args.warmup):
+            fwd_cl()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fwd_cl()
+        torch.cuda.synchronize()
+        nhwc_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        launch(ext.STAGE_ALL)  # leave the NCHW result in `out`
+        torch.cuda.synchronize()
+        del feats_cl, ws_cl
+
     # configs[2] on the side (not part of `value`): backward w.r.t. the features, same shapes
     bwd_ms = None
     if world == 1:
@@ -249,6 +275,11 @@ def main():
                                     "GB/s": round(out.numel() * 4 / (fill_ms * 1e-3) / 1e9, 1),
                                     "frac_of_it": round(achieved / (out.numel() * 4 / (fill_ms * 1e-3) / 1e9), 4)}},
         "cpu_baseline": cpu,
+        "channels_last_call": None if nhwc_ms is None else {
+            "what": "the same forward call with channels-last feature storage, consumed in place (no relayout); "
+                    "K calls after W warm-up calls; not part of `value` (BASELINE's contract is NCHW)",
+            "ms_per_call": round(nhwc_ms, 5), "ROIs/s": round(R / (nhwc_ms * 1e-3), 1),
+            "frac_of_peak_whole_call": round(b_alg / (nhwc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "backward": None if bwd_ms is None else {
             "what": "configs[2]: grad w.r.t. the features, same shapes, rroi_align_backward_hip (gather path), "
                     "wall time per call over 50 calls; not part of `value`",
