@@ -528,7 +528,9 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
         unsigned sub_shift = 3;  // 8 lanes = one chunk
         while ((1u << sub_shift) < 8u * (unsigned)nchunks && sub_shift < 6) ++sub_shift;
         const unsigned groups_per_block = 256u >> sub_shift;
-        const long gblocks = ceil_div((long)KL.keys, (long)groups_per_block);
+        // whole groups of 8 key tiles (the kernel deals the tiles of a group to the 8 XCDs)
+        const long wg_per_tile = 32 / groups_per_block;  // 1, 2, 4 or 8
+        const long gblocks = ceil_div(ceil_div((long)KL.keys, 32L), 8L) * 8L * wg_per_tile;
         hipLaunchKernelGGL(rroi_bwd_gather_kernel, dim3((unsigned)gblocks), dim3(256), 0, stream, ws.tdT,
                            ws.off, ws.bsum, ws.pairs, ws.gcm, channels, height, width, pitch, nchunks,
                            lines_per_chunk, sub_shift, KL, make_fastdiv(KL.Ht * KL.Wt),

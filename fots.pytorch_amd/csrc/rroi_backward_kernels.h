@@ -194,7 +194,14 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     const uint2* __restrict__ pairs, float* __restrict__ gcm, int C, int height, int width, int pitch,
     int nchunks, unsigned lines_per_chunk, unsigned sub_shift, KeyLayout L, FastDiv div_bt, FastDiv div_wt)
 {
-    const unsigned tid = blockIdx.x * 256u + threadIdx.x;
+    // Workgroup -> keys: the G = 2^(sub_shift-3) workgroups that cover one 8 x 4 key tile get
+    // block indices that are equal modulo 8, i.e. run on ONE XCD: neighbouring pixels share
+    // source lines (the 2 x 2 footprint of a bin), and only an XCD's own L2 can serve them twice.
+    const unsigned gshift = sub_shift - 3u;            // log2(workgroups per key tile)
+    const unsigned bq = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    const unsigned tile = ((bq >> gshift) << 3) + xcd;  // 8 tiles in flight, one per XCD
+    const unsigned wg = (tile << gshift) + (bq & ((1u << gshift) - 1u));
+    const unsigned tid = wg * 256u + threadIdx.x;
     const unsigned sub = 1u << sub_shift;              // lanes per pixel (8..64)
     const unsigned sl = tid & (sub - 1u);              // lane within the pixel's group
     const unsigned key = tid >> sub_shift;
@@ -210,27 +217,41 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     const unsigned quad = sl & 7u;
     const unsigned slice_px = (unsigned)height * (unsigned)pitch;
     const v4f z4 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int kDepth = 8;
+#ifndef RROI_GATHER_DEPTH
+#define RROI_GATHER_DEPTH 8
+#endif
+    constexpr int kDepth = RROI_GATHER_DEPTH;
     // channel passes of `sub / 8` chunks each (one pass when C <= 256)
     for (unsigned k0 = 0; k0 < (unsigned)nchunks; k0 += sub >> 3) {
         const unsigned k = k0 + (sl >> 3);
         const bool c_ok = k < (unsigned)nchunks && k * kChunk + quad * 4u < (unsigned)C;
         const float* src = tdT + ((size_t)k * lines_per_chunk) * kChunk + quad * 4u;
         v4f acc = z4;
-        for (unsigned i = beg; i < end; i += kDepth) {
-            uint2 e[kDepth];
-            v4f g[kDepth];
+        // The walk is a chain of dependent memory round trips (offsets -> records -> data), and
+        // the kernel is bound by that chain, not by bytes.  So the records are fetched `sub` at a
+        // time -- lane j of the group loads record j, one coalesced access -- and handed round
+        // with shuffles; only the data loads remain in the loop.
+        const unsigned group_base = (threadIdx.x & 63u) & ~(sub - 1u);
+        for (unsigned base = beg; base < end; base += sub) {
+            const unsigned m = min(sub, end - base);
+            const uint2 rec = sl < m ? pairs[base + sl] : make_uint2(0u, 0u);
+            for (unsigned j = 0; j < m; j += kDepth) {
+                v4f g[kDepth];
+                unsigned wb[kDepth];
 #pragma unroll
-            for (int d = 0; d < kDepth; ++d) e[d] = i + d < end ? pairs[i + d] : make_uint2(0u, 0u);
+                for (int d = 0; d < kDepth; ++d) {
+                    const int from = (int)(group_base + j + d);
+                    const unsigned line = (unsigned)__shfl((int)rec.x, from, kWave);
+                    wb[d] = (unsigned)__shfl((int)rec.y, from, kWave);
+                    g[d] = (c_ok && j + d < m) ? *reinterpret_cast<const v4f*>(src + (size_t)line * kChunk) : z4;
+                }
 #pragma unroll
-            for (int d = 0; d < kDepth; ++d)
-                g[d] = (c_ok && i + d < end) ? *reinterpret_cast<const v4f*>(src + (size_t)e[d].x * kChunk) : z4;
-#pragma unroll
-            for (int d = 0; d < kDepth; ++d) {
-                if (i + d < end) {
-                    // kernel.cu:260-263: v_k = w_k * top_diff, then one add per tap
-                    acc += g[d] * as_f(e[d].y & 0x7fffffffu);
-                    if (e[d].y & 0x80000000u) acc += g[d] * 0.0f;
+                for (int d = 0; d < kDepth; ++d) {
+                    if (j + d < m) {
+                        // kernel.cu:260-263: v_k = w_k * top_diff, then one add per tap
+                        acc += g[d] * as_f(wb[d] & 0x7fffffffu);
+                        if (wb[d] & 0x80000000u) acc += g[d] * 0.0f;
+                    }
                 }
             }
         }
