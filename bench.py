@@ -225,7 +225,23 @@ def main():
             bwd()
         torch.cuda.synchronize()
         bwd_ms = (time.perf_counter() - t0) / 50 * 1e3
-        del gout, ws_b, gin
+        gout_cl = gout.contiguous(memory_format=torch.channels_last)  # storage (R, PH, PW, C)
+
+        def bwd_cl():
+            st = ext._lib.rroi_align_backward_layout_hip(gout_cl.data_ptr(), ext.LAYOUT_NHWC, c["scale"], 1, R,
+                                                         c["H"], c["W"], c["C"], c["PH"], c["PW"], rois.data_ptr(),
+                                                         gin.data_ptr(), ws_b.data_ptr(), nb_b, ext.PATH_TILED, stream)
+            if st != 1:
+                raise RuntimeError(f"rroi_align_backward_layout_hip -> {st}")
+        for _ in range(10):
+            bwd_cl()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            bwd_cl()
+        torch.cuda.synchronize()
+        bwd_cl_ms = (time.perf_counter() - t0) / 50 * 1e3
+        del gout, gout_cl, ws_b, gin
 
     if rank != 0:
         if dist is not None:
@@ -283,7 +299,8 @@ def main():
         "backward": None if bwd_ms is None else {
             "what": "configs[2]: grad w.r.t. the features, same shapes, rroi_align_backward_hip (gather path), "
                     "wall time per call over 50 calls; not part of `value`",
-            "ms_per_call": round(bwd_ms, 5)},
+            "ms_per_call": round(bwd_ms, 5),
+            "ms_per_call_channels_last_grad": round(bwd_cl_ms, 5)},
     }
     print(json.dumps(line))
     if dist is not None:

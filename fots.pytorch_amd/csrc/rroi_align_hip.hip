@@ -437,7 +437,22 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
                             float* bottom_diff, void* workspace, size_t workspace_bytes, int path,
                             void* stream_)
 {
+    return rroi_align_backward_layout_hip(top_diff, RROI_LAYOUT_NCHW, spatial_scale, batch_size, num_rois,
+                                          height, width, channels, pooled_height, pooled_width, rois,
+                                          bottom_diff, workspace, workspace_bytes, path, stream_);
+}
+
+int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, float spatial_scale,
+                                   int batch_size, int num_rois, int height, int width, int channels,
+                                   int pooled_height, int pooled_width, const float* rois,
+                                   float* bottom_diff, void* workspace, size_t workspace_bytes,
+                                   int path, void* stream_)
+{
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (top_diff_layout != RROI_LAYOUT_NCHW && top_diff_layout != RROI_LAYOUT_NHWC) return 0;
+    const bool td_nhwc = top_diff_layout == RROI_LAYOUT_NHWC;
+    // a channels-last top_diff is consumed in place by the gather formulation only
+    if (td_nhwc && (channels % 4 != 0 || path == RROI_PATH_DIRECT || path == RROI_PATH_TILED_ATOMIC)) return 0;
     if (!shape_ok(batch_size, num_rois, height, width, channels, pooled_height, pooled_width))
         return 0;
     if (path != RROI_PATH_AUTO && path != RROI_PATH_DIRECT && path != RROI_PATH_TILED &&
@@ -450,9 +465,9 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
     if (num_rois == 0) return status_of(hipMemsetAsync(bottom_diff, 0, in_bytes, stream));
     if (!top_diff || !rois) return 0;
 
-    const bool tiled = path == RROI_PATH_AUTO
-                           ? pick_tiled_bwd(batch_size, channels, height, width, num_rois, NB)
-                           : path != RROI_PATH_DIRECT;
+    const bool tiled = td_nhwc || (path == RROI_PATH_AUTO
+                                       ? pick_tiled_bwd(batch_size, channels, height, width, num_rois, NB)
+                                       : path != RROI_PATH_DIRECT);
     if (!tiled) {
         hipError_t e = hipMemsetAsync(bottom_diff, 0, in_bytes, stream);
         if (e != hipSuccess) return status_of(e);
@@ -467,6 +482,7 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
 
     const BwdWorkspace ws = carve_bwd(workspace, batch_size, channels, height, width, num_rois, NB);
     if (!workspace || workspace_bytes < ws.bytes) return 0;
+    if (td_nhwc && (!ws.gather_ok || (size_t)num_rois * NB >= (1ull << 32))) return 0;
     const int nchunks = ceil_div(channels, kChunk);
     const int pitch = row_pitch(width);
     const int ptiles = ceil_div((long)HW, kRelayoutPx);
@@ -480,8 +496,12 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
         const KeyLayout KL = ws.keys;
         hipError_t e = hipMemsetAsync(ws.cnt, 0, (size_t)KL.keys * sizeof(int), stream);
         if (e != hipSuccess) return status_of(e);
+        // list entries name a 32-channel line of top_diff: in the relaid-out copy
+        // (R, nchunks, NB + 1, 32), or in a channels-last top_diff (R, NB, C) consumed in place
         const unsigned lines_per_chunk = (unsigned)NB + 1u;
-        const unsigned lines_per_roi = lines_per_chunk * (unsigned)nchunks;
+        const unsigned lines_per_roi = td_nhwc ? (unsigned)NB : lines_per_chunk * (unsigned)nchunks;
+        const unsigned chunk_stride = td_nhwc ? (unsigned)kChunk : lines_per_chunk * (unsigned)kChunk;
+        const unsigned line_stride = td_nhwc ? (unsigned)channels : (unsigned)kChunk;
         // one pair block per CU, looping over the bins: the pair passes need outstanding atomics,
         // not CU slots -- more blocks only take residency from the relayout (207 -> 197 us per call)
         int pblocks = ceil_div((long)num_rois * NB, 256);
@@ -491,7 +511,7 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
         // forward's, with R "images" of PH x PW "pixels" and the masked bins skipped:
         // top_diff (R, C, NB) -> chunk-major (R, nchunks, NB + 1, 32)
         const int tt = ceil_div(NB, kRelayoutPx);
-        const long tiles = (long)tt * nchunks * num_rois;
+        const long tiles = td_nhwc ? 0 : (long)tt * nchunks * num_rois;  // nothing to relay out
         if (tiles >= (1L << 31)) return 0;
         long unit = nchunks;
         while (unit % 8) unit += nchunks;  // whole groups of chunks per launch and per grid step
@@ -531,10 +551,10 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
         // whole groups of 8 key tiles (the kernel deals the tiles of a group to the 8 XCDs)
         const long wg_per_tile = 32 / groups_per_block;  // 1, 2, 4 or 8
         const long gblocks = ceil_div(ceil_div((long)KL.keys, 32L), 8L) * 8L * wg_per_tile;
-        hipLaunchKernelGGL(rroi_bwd_gather_kernel, dim3((unsigned)gblocks), dim3(256), 0, stream, ws.tdT,
-                           ws.off, ws.bsum, ws.pairs, ws.gcm, channels, height, width, pitch, nchunks,
-                           lines_per_chunk, sub_shift, KL, make_fastdiv(KL.Ht * KL.Wt),
-                           make_fastdiv(KL.Wt));
+        hipLaunchKernelGGL(rroi_bwd_gather_kernel, dim3((unsigned)gblocks), dim3(256), 0, stream,
+                           td_nhwc ? top_diff : ws.tdT, ws.off, ws.bsum, ws.pairs, ws.gcm, channels, height,
+                           width, pitch, nchunks, chunk_stride, line_stride, sub_shift, KL,
+                           make_fastdiv(KL.Ht * KL.Wt), make_fastdiv(KL.Wt));
         st = launch_status();
         if (st != 1) return st;
     } else {

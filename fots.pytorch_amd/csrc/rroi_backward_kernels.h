@@ -192,7 +192,8 @@ __global__ __launch_bounds__(1024) void rroi_scan2_kernel(unsigned* __restrict__
 __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     const float* __restrict__ tdT, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
     const uint2* __restrict__ pairs, float* __restrict__ gcm, int C, int height, int width, int pitch,
-    int nchunks, unsigned lines_per_chunk, unsigned sub_shift, KeyLayout L, FastDiv div_bt, FastDiv div_wt)
+    int nchunks, unsigned chunk_stride, unsigned line_stride, unsigned sub_shift, KeyLayout L,
+    FastDiv div_bt, FastDiv div_wt)
 {
     // Workgroup -> keys: the G = 2^(sub_shift-3) workgroups that cover one 8 x 4 key tile get
     // block indices that are equal modulo 8, i.e. run on ONE XCD: neighbouring pixels share
@@ -225,7 +226,10 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     for (unsigned k0 = 0; k0 < (unsigned)nchunks; k0 += sub >> 3) {
         const unsigned k = k0 + (sl >> 3);
         const bool c_ok = k < (unsigned)nchunks && k * kChunk + quad * 4u < (unsigned)C;
-        const float* src = tdT + ((size_t)k * lines_per_chunk) * kChunk + quad * 4u;
+        // where the 32 channels of chunk k of list entry `line` live: the relaid-out top_diff
+        // (chunk_stride = (NB+1)*32, line_stride = 32) or a channels-last top_diff consumed in
+        // place (chunk_stride = 32, line_stride = C), both in floats
+        const float* src = tdT + (size_t)k * chunk_stride + quad * 4u;
         v4f acc = z4;
         // The walk is a chain of dependent memory round trips (offsets -> records -> data), and
         // the kernel is bound by that chain, not by bytes.  So the records are fetched `sub` at a
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
                     const int from = (int)(group_base + j + d);
                     const unsigned line = (unsigned)__shfl((int)rec.x, from, kWave);
                     wb[d] = (unsigned)__shfl((int)rec.y, from, kWave);
-                    g[d] = (c_ok && j + d < m) ? *reinterpret_cast<const v4f*>(src + (size_t)line * kChunk) : z4;
+                    g[d] = (c_ok && j + d < m) ? *reinterpret_cast<const v4f*>(src + (size_t)line * line_stride) : z4;
                 }
 #pragma unroll
                 for (int d = 0; d < kDepth; ++d) {

@@ -45,6 +45,8 @@ _lib.rroi_align_forward_stages_hip.restype = _i
 _lib.rroi_align_forward_stages_hip.argtypes = [_vp, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _i, _vp]
 _lib.rroi_align_backward_hip.restype = _i
 _lib.rroi_align_backward_hip.argtypes = [_vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]
+_lib.rroi_align_backward_layout_hip.restype = _i
+_lib.rroi_align_backward_layout_hip.argtypes = [_vp, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]
 _lib.rroi_align_bin_centres_hip.restype = _i
 _lib.rroi_align_bin_centres_hip.argtypes = [_f, _i, _i, _i, _i, _i, _vp, _vp, _vp]
 _lib.rroi_align_quads_to_rois_hip.restype = _i
@@ -63,7 +65,7 @@ EXPORTS = (
     "rroi_align_backward_hip", "rroi_align_forward_stages_hip", "rroi_align_forward_workspace_bytes",
     "rroi_align_backward_workspace_bytes", "rroi_align_bin_centres_hip",
     "rroi_align_sincos_probe_hip", "rroi_align_quads_to_rois_hip", "rroi_align_hip_version",
-    "rroi_ctc_greedy_decode_hip",
+    "rroi_ctc_greedy_decode_hip", "rroi_align_backward_layout_hip",
 )
 
 
@@ -139,18 +141,26 @@ def backward(grad_output: torch.Tensor, rois: torch.Tensor, feature_size, spatia
     B, C, H, W = (int(v) for v in feature_size)
     if grad_output.dim() != 4 or grad_output.size(1) != C or grad_output.size(0) != rois.size(0):
         raise ValueError("grad_output must be (R,C,PH,PW) matching rois and the feature size")
-    grad_output = grad_output.contiguous()
-    rois = rois.contiguous()
     R, _, ph, pw = grad_output.shape
+    # channels_last storage (R, PH, PW, C) -- what autograd hands over when the recognition head
+    # runs in channels_last -- is consumed in place by the gather path: no .contiguous() copy of
+    # the 256 MiB, no relayout pass
+    layout = LAYOUT_NCHW
+    if (not grad_output.is_contiguous() and grad_output.is_contiguous(memory_format=torch.channels_last)
+            and C % 4 == 0 and path in (PATH_AUTO, PATH_TILED) and R > 0):
+        layout = LAYOUT_NHWC
+    else:
+        grad_output = grad_output.contiguous()
+    rois = rois.contiguous()
     with torch.cuda.device_of(grad_output):
         grad_in = torch.empty((B, C, H, W), dtype=torch.float32, device=grad_output.device)
         if grad_in.numel() == 0:
             return grad_in
         nbytes = 0 if path == PATH_DIRECT else _lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, ph, pw)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=grad_output.device)
-        st = _lib.rroi_align_backward_hip(grad_output.data_ptr(), float(spatial_scale), B, R, H, W,
-                                          C, ph, pw, rois.data_ptr(), grad_in.data_ptr(),
-                                          ws.data_ptr(), nbytes, path, _stream())
+        st = _lib.rroi_align_backward_layout_hip(grad_output.data_ptr(), layout, float(spatial_scale), B, R,
+                                                 H, W, C, ph, pw, rois.data_ptr(), grad_in.data_ptr(),
+                                                 ws.data_ptr(), nbytes, path, _stream())
     _check(st, "rroi_align_backward_hip")
     return grad_in
 

@@ -109,6 +109,16 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
                             float* bottom_diff, void* workspace, size_t workspace_bytes, int path,
                             void* stream);
 
+/* The same with the layout of top_diff stated: RROI_LAYOUT_NCHW (R, C, PH, PW) as above, or
+ * RROI_LAYOUT_NHWC = torch channels_last storage (R, PH, PW, C), which the gather formulation
+ * consumes in place -- no relayout pass (needs C % 4 == 0; path AUTO or TILED).  This is what
+ * autograd hands over when the recognition head runs in channels_last. */
+int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, float spatial_scale,
+                                   int batch_size, int num_rois, int height, int width, int channels,
+                                   int pooled_height, int pooled_width, const float* rois,
+                                   float* bottom_diff, void* workspace, size_t workspace_bytes,
+                                   int path, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * 3. The callers' ROI construction, on the device.
  *    quads (n, 8) fp32 [x0,y0,x1,y1,x2,y2,x3,y3] -> rois (n, 6) fp32 rows for the

@@ -191,6 +191,32 @@ def test_backward_many_rois_on_one_pixel(ext, oracle):
         assert np.array_equal(g == 0, gwant == 0)
 
 
+@pytest.mark.parametrize("name", ["mid_c64", "batch3", "train_11xceil"])
+def test_backward_channels_last_grad(ext, oracle, name):
+    """grad_output in channels_last storage (a channels_last recognition head) is consumed in place."""
+    f, r, ph, pw, s = SHAPES[name]()
+    gout = np.random.default_rng(3).standard_normal((len(r), f.shape[1], ph, pw)).astype(np.float32)
+    want = oracle.backward_c(gout, r, f.shape, s)
+    G = dev(gout).contiguous(memory_format=torch.channels_last)
+    assert not G.is_contiguous()
+    for p in (ext.PATH_AUTO, ext.PATH_TILED):
+        got = ext.backward(G, dev(r), f.shape, s, path=p).cpu().numpy()
+        assert np.abs(got - want).max() <= BWD_RTOL * max(1.0, float(np.abs(want).max()))
+    # paths that need NCHW fall back to a contiguous copy
+    got = ext.backward(G, dev(r), f.shape, s, path=ext.PATH_DIRECT).cpu().numpy()
+    assert np.abs(got - want).max() <= BWD_RTOL * max(1.0, float(np.abs(want).max()))
+    # the C-ABI refuses the combinations it cannot serve
+    R, C = gout.shape[:2]
+    B, _, H, W = f.shape
+    nb = ext._lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, ph, pw)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    gin = torch.empty(f.shape, device="cuda")
+    st = ext._lib.rroi_align_backward_layout_hip(G.data_ptr(), ext.LAYOUT_NHWC, s, B, R, H, W, C, ph, pw,
+                                                 dev(r).data_ptr(), gin.data_ptr(), ws.data_ptr(), nb,
+                                                 ext.PATH_DIRECT, torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+
+
 def test_backward_nonfinite_gradients(ext, oracle):
     """The reference sends w*g AND 0*g to a pixel that two taps of a bin alias (kernel.cu:260-274):
     an infinite g there makes the pixel NaN, not inf.  Same set of non-finite pixels on every path;

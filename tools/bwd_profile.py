@@ -38,6 +38,23 @@ for name, path, n in (("tiled (gather)", ext.PATH_TILED, 50), ("tiled_atomic (sc
         call(path)
     torch.cuda.synchronize()
     print(f"backward cfg3 {name}: {(time.perf_counter() - t0) / n * 1e6:.1f} us  (workspace {nb / 1e6:.1f} MB)")
+g_cl = g.contiguous(memory_format=torch.channels_last)
+
+
+def call_cl():
+    rc = ext._lib.rroi_align_backward_layout_hip(g_cl.data_ptr(), ext.LAYOUT_NHWC, 0.25, B, 512, H, W, C, 8, 64,
+                                                 R.data_ptr(), gin.data_ptr(), ws.data_ptr(), nb, ext.PATH_TILED, st)
+    assert rc == 1, rc
+
+
+for _ in range(3):
+    call_cl()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50):
+    call_cl()
+torch.cuda.synchronize()
+print(f"backward cfg3 tiled (gather), channels-last top_diff consumed in place: {(time.perf_counter() - t0) / 50 * 1e6:.1f} us")
 if os.environ.get("RROI_BWD_SWEEP") and hasattr(ext._lib, "rroi_align_debug_set_bwd_relayout_aux"):  # make EXPLORE=1
     for raux in (0, 2, 16):
         ext._lib.rroi_align_debug_set_bwd_relayout_aux(raux)
