@@ -72,4 +72,11 @@ for t in range(trials):
         if not e <= 1e-4 * sc:
             bad += 1
             print(f"BWD MISMATCH trial {t} path {p}: C={C} {H}x{W} B={B} {ph}x{pw} s={s} R={R}: err {e} scale {sc}")
+    if C % 4 == 0:
+        Gcl = G.contiguous(memory_format=torch.channels_last)
+        g = ext.backward(Gcl, Rr, f.shape, s).cpu().numpy()
+        e = float(np.abs(g - gw).max())
+        if not e <= 1e-4 * sc:
+            bad += 1
+            print(f"BWD MISMATCH trial {t} channels-last grad: C={C} {H}x{W} B={B} {ph}x{pw} s={s} R={R}: err {e} scale {sc}")
 print(f"fuzz: {trials} trials, {bad} mismatches")
