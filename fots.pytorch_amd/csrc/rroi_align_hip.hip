@@ -280,14 +280,46 @@ int rroi_align_forward_hip(const float* features, int feature_layout, float spat
                                          path, RROI_STAGE_ALL, stream_);
 }
 
+static int forward_impl(const float* features, int feature_layout, int top_layout, float spatial_scale,
+                        int batch_size, int num_rois, int height, int width, int channels,
+                        int pooled_height, int pooled_width, const float* rois, float* top_data,
+                        void* workspace, size_t workspace_bytes, int path, int stages, void* stream_);
+
 int rroi_align_forward_stages_hip(const float* features, int feature_layout, float spatial_scale,
                                   int batch_size, int num_rois, int height, int width,
                                   int channels, int pooled_height, int pooled_width,
                                   const float* rois, float* top_data, void* workspace,
                                   size_t workspace_bytes, int path, int stages, void* stream_)
 {
+    return forward_impl(features, feature_layout, RROI_LAYOUT_NCHW, spatial_scale, batch_size, num_rois,
+                        height, width, channels, pooled_height, pooled_width, rois, top_data, workspace,
+                        workspace_bytes, path, stages, stream_);
+}
+
+int rroi_align_forward_layout_hip(const float* features, int feature_layout, int top_layout,
+                                  float spatial_scale, int batch_size, int num_rois, int height,
+                                  int width, int channels, int pooled_height, int pooled_width,
+                                  const float* rois, float* top_data, void* workspace,
+                                  size_t workspace_bytes, int path, void* stream_)
+{
+    return forward_impl(features, feature_layout, top_layout, spatial_scale, batch_size, num_rois, height,
+                        width, channels, pooled_height, pooled_width, rois, top_data, workspace,
+                        workspace_bytes, path, RROI_STAGE_ALL, stream_);
+}
+
+static int forward_impl(const float* features, int feature_layout, int top_layout, float spatial_scale,
+                        int batch_size, int num_rois, int height, int width, int channels,
+                        int pooled_height, int pooled_width, const float* rois, float* top_data,
+                        void* workspace, size_t workspace_bytes, int path, int stages, void* stream_)
+{
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if ((stages & ~RROI_STAGE_ALL) || stages == 0) return 0;
+    if (top_layout != RROI_LAYOUT_NCHW && top_layout != RROI_LAYOUT_NHWC) return 0;
+    const bool out_nhwc = top_layout == RROI_LAYOUT_NHWC;
+    // channels-last crops are written by the tiled kernel only: 16-byte channel quads
+    if (out_nhwc && (channels % 4 != 0 || path == RROI_PATH_DIRECT ||
+                     (long)pooled_height * pooled_width * channels * 4 >= (1L << 31)))
+        return 0;
     if (!shape_ok(batch_size, num_rois, height, width, channels, pooled_height, pooled_width))
         return 0;
     if (feature_layout != RROI_LAYOUT_NCHW && feature_layout != RROI_LAYOUT_NHWC) return 0;
@@ -297,7 +329,9 @@ int rroi_align_forward_stages_hip(const float* features, int feature_layout, flo
     const int NB = pooled_height * pooled_width;
 
     bool tiled;
-    if (path == RROI_PATH_AUTO)
+    if (out_nhwc)
+        tiled = true;
+    else if (path == RROI_PATH_AUTO)
         tiled = feature_layout == RROI_LAYOUT_NHWC ||
                 pick_tiled_fwd(batch_size, channels, height, width, num_rois, NB);
     else
@@ -373,7 +407,11 @@ int rroi_align_forward_stages_hip(const float* features, int feature_layout, flo
     hipLaunchKernelGGL((rroi_fwd_tiled_kernel<VEC, AUX>), dim3(grid), dim3(kWave), 0, stream, map,   \
                        ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,        \
                        batch_size, nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
-        if (NB % 4 != 0) RROI_LAUNCH_FWD(false, 2);
+        if (out_nhwc)
+            hipLaunchKernelGGL((rroi_fwd_tiled_kernel<true, 2, true>), dim3(grid), dim3(kWave), 0, stream, map,
+                               ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,
+                               batch_size, nchunks, ntiles, lay, dt, dp, g_fwd_dbg);
+        else if (NB % 4 != 0) RROI_LAUNCH_FWD(false, 2);
         else if (g_store_aux == 0) RROI_LAUNCH_FWD(true, 0);    // exploration only
         else if (g_store_aux == 16) RROI_LAUNCH_FWD(true, 16);  // exploration only
         else if (g_store_aux == 3) RROI_LAUNCH_FWD(true, 3);    // exploration only: pure nt (sc0 nt)

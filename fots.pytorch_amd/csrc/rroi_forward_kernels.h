@@ -177,7 +177,7 @@ __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois,
 // The three phases of consecutive items are interleaved around the store burst, see the
 // loop at the end.
 // ------------------------------------------------------------------------------------
-template <bool VEC_STORE, int AUX>
+template <bool VEC_STORE, int AUX, bool ONHWC = false>
 __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
@@ -355,6 +355,28 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     // the store acknowledgements.  (Also the ablation knob: dbg & 1 drops the output stores.)
     auto store_tile = [&](unsigned n, unsigned t, unsigned long long cur_mask, bool live) {
         live = live && !(dbg & 1);
+        if (ONHWC) {
+            // channels-last output (R, PH*PW, C): lane = (channel quad q, bin b) as in phase B; a
+            // store covers 8 bins x 128 B, the 32 channels of this chunk in each bin's 4*C-byte
+            // line.  The tile is read back along its columns (the mapping put() wrote it with).
+            float* obase = out + (size_t)n * NB * C;
+            const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, (unsigned)NB * (unsigned)C * 4u);
+            const bool q_ok = k * kChunk + q * 4 < (unsigned)C;
+#pragma unroll
+            for (int it8 = 0; it8 < kIters; ++it8) {
+                const unsigned bl = (unsigned)it8 * kBinsPerIter + b;   // bin within the tile
+                const float* tr = t_row + (bl ^ wswz);
+                const bool on = (cur_mask >> bl) & 1ull;
+                const v4f o = {on ? tr[0] : 0.f, on ? tr[kTStride] : 0.f, on ? tr[2 * kTStride] : 0.f,
+                               on ? tr[3 * kTStride] : 0.f};
+                const unsigned bin = t * kTileBins + bl;
+                const unsigned off = (bin * (unsigned)C + k * kChunk + q * 4u) * 4u;
+                const unsigned o_off = (live && q_ok && bin < (unsigned)NB) ? off : kOOB;
+                if (AUX == 2 && it8 == 0) buf_store<kMinorAux>(ws, o_off, o);
+                else buf_store<AUX>(ws, o_off, o);
+            }
+            return;
+        }
         // descriptor over this (roi, chunk) block of the output: rows >= C fall out of range
         float* obase = out + ((size_t)n * C + k * kChunk) * NB;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, chans_here * (unsigned)NB * 4u);

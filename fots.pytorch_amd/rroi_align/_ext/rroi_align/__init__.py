@@ -41,6 +41,8 @@ _lib.rroi_align_backward_workspace_bytes.restype = _sz
 _lib.rroi_align_backward_workspace_bytes.argtypes = [_i] * 7
 _lib.rroi_align_forward_hip.restype = _i
 _lib.rroi_align_forward_hip.argtypes = [_vp, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]
+_lib.rroi_align_forward_layout_hip.restype = _i
+_lib.rroi_align_forward_layout_hip.argtypes = [_vp, _i, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]
 _lib.rroi_align_forward_stages_hip.restype = _i
 _lib.rroi_align_forward_stages_hip.argtypes = [_vp, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _i, _vp]
 _lib.rroi_align_backward_hip.restype = _i
@@ -65,7 +67,7 @@ EXPORTS = (
     "rroi_align_backward_hip", "rroi_align_forward_stages_hip", "rroi_align_forward_workspace_bytes",
     "rroi_align_backward_workspace_bytes", "rroi_align_bin_centres_hip",
     "rroi_align_sincos_probe_hip", "rroi_align_quads_to_rois_hip", "rroi_align_hip_version",
-    "rroi_ctc_greedy_decode_hip", "rroi_align_backward_layout_hip",
+    "rroi_ctc_greedy_decode_hip", "rroi_align_backward_layout_hip", "rroi_align_forward_layout_hip",
 )
 
 
@@ -98,8 +100,10 @@ def _require_cuda_f32(t: torch.Tensor, name: str) -> None:
 
 # --------------------------------------------------------------------------- native path
 def forward(features: torch.Tensor, rois: torch.Tensor, pooled_height: int, pooled_width: int,
-            spatial_scale: float, path: int = PATH_AUTO) -> torch.Tensor:
-    """(B,C,H,W) x (R,6) -> (R,C,PH,PW).  NCHW-contiguous or channels_last features."""
+            spatial_scale: float, path: int = PATH_AUTO, channels_last_out: bool = False) -> torch.Tensor:
+    """(B,C,H,W) x (R,6) -> (R,C,PH,PW).  NCHW-contiguous or channels_last features.
+    channels_last_out: return the crops in channels_last storage (same values) for a recognition
+    head that runs in channels_last; needs C % 4 == 0 and the tiled path."""
     _require_cuda_f32(features, "features")
     _require_cuda_f32(rois, "rois")
     if features.dim() != 4:
@@ -120,15 +124,19 @@ def forward(features: torch.Tensor, rois: torch.Tensor, pooled_height: int, pool
     else:
         features, layout = features.contiguous(), LAYOUT_NCHW
     rois = rois.contiguous()
+    if channels_last_out and (C % 4 != 0 or path == PATH_DIRECT):
+        raise ValueError("channels_last_out needs C % 4 == 0 and the tiled path")
     with torch.cuda.device_of(features):
-        out = torch.empty((R, C, ph, pw), dtype=torch.float32, device=features.device)
+        out = torch.empty((R, C, ph, pw), dtype=torch.float32, device=features.device,
+                          memory_format=torch.channels_last if channels_last_out else torch.contiguous_format)
         if R == 0 or out.numel() == 0:
             return out
         nbytes = 0 if path == PATH_DIRECT else _lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, layout)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=features.device)
-        st = _lib.rroi_align_forward_hip(features.data_ptr(), layout, float(spatial_scale), B, R, H,
-                                         W, C, ph, pw, rois.data_ptr(), out.data_ptr(),
-                                         ws.data_ptr(), nbytes, path, _stream())
+        st = _lib.rroi_align_forward_layout_hip(features.data_ptr(), layout,
+                                                LAYOUT_NHWC if channels_last_out else LAYOUT_NCHW,
+                                                float(spatial_scale), B, R, H, W, C, ph, pw, rois.data_ptr(),
+                                                out.data_ptr(), ws.data_ptr(), nbytes, path, _stream())
     _check(st, "rroi_align_forward_hip")
     return out
 

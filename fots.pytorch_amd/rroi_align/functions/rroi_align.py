@@ -17,13 +17,14 @@ from .._ext import rroi_align
 
 class _RRoiAlignOp(Function):
     @staticmethod
-    def forward(ctx, features, rois, pooled_height, pooled_width, spatial_scale):
+    def forward(ctx, features, rois, pooled_height, pooled_width, spatial_scale, channels_last_out=False):
         ctx.pooled_height = pooled_height
         ctx.pooled_width = pooled_width
         ctx.spatial_scale = spatial_scale
         ctx.feature_size = features.size()
         ctx.save_for_backward(rois)
-        return rroi_align.forward(features, rois, pooled_height, pooled_width, spatial_scale)
+        return rroi_align.forward(features, rois, pooled_height, pooled_width, spatial_scale,
+                                  channels_last_out=channels_last_out)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -33,16 +34,18 @@ class _RRoiAlignOp(Function):
         if ctx.needs_input_grad[0]:
             grad_input = rroi_align.backward(grad_output, rois, ctx.feature_size,
                                              ctx.spatial_scale)
-        return grad_input, None, None, None, None
+        return grad_input, None, None, None, None, None
 
 
 class RRoiAlignFunction(object):
     """``RRoiAlignFunction(ph, pw, scale)(features, rois) -> (R, C, ph, pw)``."""
 
-    def __init__(self, pooled_height, pooled_width, spatial_scale):
+    def __init__(self, pooled_height, pooled_width, spatial_scale, channels_last_out=False):
         self.pooled_width = pooled_width
         self.pooled_height = pooled_height
         self.spatial_scale = spatial_scale
+        # extension: crops in channels_last storage for a channels_last recognition head
+        self.channels_last_out = bool(channels_last_out)
         self.feature_size = None
         self.rois = None
 
@@ -50,14 +53,14 @@ class RRoiAlignFunction(object):
         self.feature_size = features.size()
         self.rois = rois
         return _RRoiAlignOp.apply(features, rois, int(self.pooled_height), int(self.pooled_width),
-                                  float(self.spatial_scale))
+                                  float(self.spatial_scale), self.channels_last_out)
 
     # the legacy Function's two methods, callable by hand as in torch 0.4
     def forward(self, features, rois):
         self.feature_size = features.size()
         self.rois = rois
         return rroi_align.forward(features, rois, int(self.pooled_height), int(self.pooled_width),
-                                  float(self.spatial_scale))
+                                  float(self.spatial_scale), channels_last_out=self.channels_last_out)
 
     def backward(self, grad_output):
         assert self.feature_size is not None and grad_output.is_cuda

@@ -86,6 +86,17 @@ int rroi_align_forward_hip(const float* features, int feature_layout, float spat
                            float* top_data, void* workspace, size_t workspace_bytes, int path,
                            void* stream);
 
+/* The same with the layout of the crops stated: RROI_LAYOUT_NCHW (R, C, PH, PW) -- the reference
+ * contract, what rroi_align_forward_hip writes -- or RROI_LAYOUT_NHWC = torch channels_last
+ * storage (R, PH, PW, C), for a recognition head that runs in channels_last (MIOpen's preferred
+ * layout): the first convolution then needs no 256 MiB relayout of its input.  Same values,
+ * element for element.  Needs C % 4 == 0; tiled path only. */
+int rroi_align_forward_layout_hip(const float* features, int feature_layout, int top_layout,
+                                  float spatial_scale, int batch_size, int num_rois, int height,
+                                  int width, int channels, int pooled_height, int pooled_width,
+                                  const float* rois, float* top_data, void* workspace,
+                                  size_t workspace_bytes, int path, void* stream);
+
 /* The same call split into its launches, so a harness can bracket each kernel
  * with events on `stream`: RROI_STAGE_PROLOGUE = relayout + affine table,
  * RROI_STAGE_GATHER = the gather/blend/stream-out kernel (needs the workspace a

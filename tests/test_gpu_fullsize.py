@@ -51,6 +51,9 @@ def test_cfg2_properties(ext, full):
         assert not out[n, :, :, int(rpw[n]) + 1:].any()
     # idempotent / deterministic
     assert torch.equal(ext.forward(F, R, 8, 64, 0.25), out)
+    # channels_last crops: same values in (R, PH, PW, C) storage
+    ocl = ext.forward(F, R, 8, 64, 0.25, channels_last_out=True)
+    assert ocl.is_contiguous(memory_format=torch.channels_last) and torch.equal(ocl, out)
 
 
 def test_cfg3_forward_backward(ext, oracle, full):

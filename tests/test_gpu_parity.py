@@ -191,6 +191,40 @@ def test_backward_many_rois_on_one_pixel(ext, oracle):
         assert np.array_equal(g == 0, gwant == 0)
 
 
+@pytest.mark.parametrize("name", ["mid_c64", "batch3", "train_11xceil", "c70_odd"])
+def test_forward_channels_last_output(ext, oracle, name):
+    """Crops written straight into channels_last storage: same values, element for element."""
+    f, r, ph, pw, s = SHAPES[name]()
+    C = f.shape[1]
+    if C % 4:
+        with pytest.raises(ValueError):
+            ext.forward(dev(f), dev(r), ph, pw, s, channels_last_out=True)
+        return
+    want = oracle.forward_c(f, r, ph, pw, s, threads=8)
+    for F in (dev(f), dev(f).contiguous(memory_format=torch.channels_last)):
+        got = ext.forward(F, dev(r), ph, pw, s, channels_last_out=True)
+        assert got.is_contiguous(memory_format=torch.channels_last) and got.shape == want.shape
+        assert mismatch(got.cpu().numpy(), want)[0] == 0
+    with pytest.raises(ValueError):
+        ext.forward(dev(f), dev(r), ph, pw, s, path=ext.PATH_DIRECT, channels_last_out=True)
+
+
+def test_channels_last_pipeline_through_autograd(ext, oracle):
+    """channels_last features -> channels_last crops -> channels_last gradient, through the module:
+    values and gradients equal the NCHW pipeline's (forward bit for bit)."""
+    from rroi_align.modules.rroi_align import _RRoiAlign
+    f, r, ph, pw, s = SHAPES["mid_c64"]()
+    want = oracle.forward_c(f, r, ph, pw, s, threads=8)
+    gwant = oracle.backward_c((2 * want).astype(np.float32), r, f.shape, s)
+    feats = dev(f).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    pooled = _RRoiAlign(ph, pw, s, channels_last_out=True)(feats, dev(r))
+    assert pooled.is_contiguous(memory_format=torch.channels_last)
+    assert mismatch(pooled.detach().cpu().numpy(), want)[0] == 0
+    pooled.pow(2).sum().backward()          # grad_output = 2 * pooled, channels_last
+    got = feats.grad.cpu().numpy()
+    assert np.abs(got - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max()))
+
+
 @pytest.mark.parametrize("name", ["mid_c64", "batch3", "train_11xceil"])
 def test_backward_channels_last_grad(ext, oracle, name):
     """grad_output in channels_last storage (a channels_last recognition head) is consumed in place."""
