@@ -228,7 +228,7 @@ def main():
         gout_cl = gout.contiguous(memory_format=torch.channels_last)  # storage (R, PH, PW, C)
 
         def bwd_cl():
-            st = ext._lib.rroi_align_backward_layout_hip(gout_cl.data_ptr(), ext.LAYOUT_NHWC, c["scale"], 1, R,
+            st = ext._lib.rroi_align_backward_layout_hip(gout_cl.data_ptr(), ext.LAYOUT_NHWC, ext.LAYOUT_NHWC, c["scale"], 1, R,
                                                          c["H"], c["W"], c["C"], c["PH"], c["PW"], rois.data_ptr(),
                                                          gin.data_ptr(), ws_b.data_ptr(), nb_b, ext.PATH_TILED, stream)
             if st != 1:
@@ -300,7 +300,7 @@ def main():
             "what": "configs[2]: grad w.r.t. the features, same shapes, rroi_align_backward_hip (gather path), "
                     "wall time per call over 50 calls; not part of `value`",
             "ms_per_call": round(bwd_ms, 5),
-            "ms_per_call_channels_last_grad": round(bwd_cl_ms, 5)},
+            "ms_per_call_channels_last": round(bwd_cl_ms, 5)},  # top_diff and the feature gradient both in channels_last storage
     }
     print(json.dumps(line))
     if dist is not None:

@@ -475,22 +475,26 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
                             float* bottom_diff, void* workspace, size_t workspace_bytes, int path,
                             void* stream_)
 {
-    return rroi_align_backward_layout_hip(top_diff, RROI_LAYOUT_NCHW, spatial_scale, batch_size, num_rois,
-                                          height, width, channels, pooled_height, pooled_width, rois,
-                                          bottom_diff, workspace, workspace_bytes, path, stream_);
+    return rroi_align_backward_layout_hip(top_diff, RROI_LAYOUT_NCHW, RROI_LAYOUT_NCHW, spatial_scale,
+                                          batch_size, num_rois, height, width, channels, pooled_height,
+                                          pooled_width, rois, bottom_diff, workspace, workspace_bytes, path,
+                                          stream_);
 }
 
-int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, float spatial_scale,
-                                   int batch_size, int num_rois, int height, int width, int channels,
-                                   int pooled_height, int pooled_width, const float* rois,
-                                   float* bottom_diff, void* workspace, size_t workspace_bytes,
-                                   int path, void* stream_)
+int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, int bottom_diff_layout,
+                                   float spatial_scale, int batch_size, int num_rois, int height,
+                                   int width, int channels, int pooled_height, int pooled_width,
+                                   const float* rois, float* bottom_diff, void* workspace,
+                                   size_t workspace_bytes, int path, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (top_diff_layout != RROI_LAYOUT_NCHW && top_diff_layout != RROI_LAYOUT_NHWC) return 0;
-    const bool td_nhwc = top_diff_layout == RROI_LAYOUT_NHWC;
-    // a channels-last top_diff is consumed in place by the gather formulation only
-    if (td_nhwc && (channels % 4 != 0 || path == RROI_PATH_DIRECT || path == RROI_PATH_TILED_ATOMIC)) return 0;
+    if (bottom_diff_layout != RROI_LAYOUT_NCHW && bottom_diff_layout != RROI_LAYOUT_NHWC) return 0;
+    const bool td_nhwc = top_diff_layout == RROI_LAYOUT_NHWC, bd_nhwc = bottom_diff_layout == RROI_LAYOUT_NHWC;
+    // channels-last tensors are read / written in place by the gather formulation only
+    if ((td_nhwc || bd_nhwc) &&
+        (channels % 4 != 0 || path == RROI_PATH_DIRECT || path == RROI_PATH_TILED_ATOMIC))
+        return 0;
     if (!shape_ok(batch_size, num_rois, height, width, channels, pooled_height, pooled_width))
         return 0;
     if (path != RROI_PATH_AUTO && path != RROI_PATH_DIRECT && path != RROI_PATH_TILED &&
@@ -503,7 +507,7 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, f
     if (num_rois == 0) return status_of(hipMemsetAsync(bottom_diff, 0, in_bytes, stream));
     if (!top_diff || !rois) return 0;
 
-    const bool tiled = td_nhwc || (path == RROI_PATH_AUTO
+    const bool tiled = td_nhwc || bd_nhwc || (path == RROI_PATH_AUTO
                                        ? pick_tiled_bwd(batch_size, channels, height, width, num_rois, NB)
                                        : path != RROI_PATH_DIRECT);
     if (!tiled) {
@@ -520,7 +524,7 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, f
 
     const BwdWorkspace ws = carve_bwd(workspace, batch_size, channels, height, width, num_rois, NB);
     if (!workspace || workspace_bytes < ws.bytes) return 0;
-    if (td_nhwc && (!ws.gather_ok || (size_t)num_rois * NB >= (1ull << 32))) return 0;
+    if ((td_nhwc || bd_nhwc) && (!ws.gather_ok || (size_t)num_rois * NB >= (1ull << 32))) return 0;
     const int nchunks = ceil_div(channels, kChunk);
     const int pitch = row_pitch(width);
     const int ptiles = ceil_div((long)HW, kRelayoutPx);
@@ -589,7 +593,14 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, f
         // whole groups of 8 key tiles (the kernel deals the tiles of a group to the 8 XCDs)
         const long wg_per_tile = 32 / groups_per_block;  // 1, 2, 4 or 8
         const long gblocks = ceil_div(ceil_div((long)KL.keys, 32L), 8L) * 8L * wg_per_tile;
-        hipLaunchKernelGGL(rroi_bwd_gather_kernel, dim3((unsigned)gblocks), dim3(256), 0, stream,
+        if (bd_nhwc) {
+            hipLaunchKernelGGL(rroi_bwd_gather_kernel<true>, dim3((unsigned)gblocks), dim3(256), 0, stream,
+                               td_nhwc ? top_diff : ws.tdT, ws.off, ws.bsum, ws.pairs, bottom_diff, channels,
+                               height, width, pitch, nchunks, chunk_stride, line_stride, sub_shift, KL,
+                               make_fastdiv(KL.Ht * KL.Wt), make_fastdiv(KL.Wt));
+            return launch_status();  // written in place: no relayout back
+        }
+        hipLaunchKernelGGL(rroi_bwd_gather_kernel<false>, dim3((unsigned)gblocks), dim3(256), 0, stream,
                            td_nhwc ? top_diff : ws.tdT, ws.off, ws.bsum, ws.pairs, ws.gcm, channels, height,
                            width, pitch, nchunks, chunk_stride, line_stride, sub_shift, KL,
                            make_fastdiv(KL.Ht * KL.Wt), make_fastdiv(KL.Wt));

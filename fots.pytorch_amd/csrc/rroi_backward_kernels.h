@@ -189,6 +189,7 @@ __global__ __launch_bounds__(1024) void rroi_scan2_kernel(unsigned* __restrict__
 // gather: `sub` = 8 * nchunks_pass lanes serve one pixel (lane -> chunk, channel quad); 64 / sub
 // pixels per wave; one pixel group per thread group, so the hardware's block dispatch balances
 // the (very uneven) list lengths.  The 16-byte loads of eight pairs are in flight together.
+template <bool DST_NHWC>
 __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     const float* __restrict__ tdT, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
     const uint2* __restrict__ pairs, float* __restrict__ gcm, int C, int height, int width, int pitch,
@@ -260,7 +261,11 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
             }
         }
         if (c_ok) {
-            float* dst = gcm + (((size_t)b * nchunks + k) * slice_px + (size_t)y * pitch + x) * kChunk + quad * 4u;
+            // chunk-major gradient (relaid out to NCHW afterwards), or the caller's channels-last
+            // gradient (B, H, W, C) written directly: `gcm` is then bottom_diff itself
+            float* dst = DST_NHWC
+                             ? gcm + (((size_t)b * height + y) * width + x) * (size_t)C + k * kChunk + quad * 4u
+                             : gcm + (((size_t)b * nchunks + k) * slice_px + (size_t)y * pitch + x) * kChunk + quad * 4u;
             *reinterpret_cast<v4f*>(dst) = acc;
         }
     }

@@ -48,7 +48,7 @@ _lib.rroi_align_forward_stages_hip.argtypes = [_vp, _i, _f, _i, _i, _i, _i, _i, 
 _lib.rroi_align_backward_hip.restype = _i
 _lib.rroi_align_backward_hip.argtypes = [_vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]
 _lib.rroi_align_backward_layout_hip.restype = _i
-_lib.rroi_align_backward_layout_hip.argtypes = [_vp, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]
+_lib.rroi_align_backward_layout_hip.argtypes = [_vp, _i, _i, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]
 _lib.rroi_align_bin_centres_hip.restype = _i
 _lib.rroi_align_bin_centres_hip.argtypes = [_f, _i, _i, _i, _i, _i, _vp, _vp, _vp]
 _lib.rroi_align_quads_to_rois_hip.restype = _i
@@ -142,8 +142,9 @@ def forward(features: torch.Tensor, rois: torch.Tensor, pooled_height: int, pool
 
 
 def backward(grad_output: torch.Tensor, rois: torch.Tensor, feature_size, spatial_scale: float,
-             path: int = PATH_AUTO) -> torch.Tensor:
-    """(R,C,PH,PW) -> grad w.r.t. features (B,C,H,W), NCHW contiguous."""
+             path: int = PATH_AUTO, channels_last_grad: bool = False) -> torch.Tensor:
+    """(R,C,PH,PW) -> grad w.r.t. features (B,C,H,W): NCHW contiguous, or (channels_last_grad, for a
+    channels_last backbone; needs C % 4 == 0 and the tiled path) in channels_last storage."""
     _require_cuda_f32(grad_output, "grad_output")
     _require_cuda_f32(rois, "rois")
     B, C, H, W = (int(v) for v in feature_size)
@@ -160,14 +161,17 @@ def backward(grad_output: torch.Tensor, rois: torch.Tensor, feature_size, spatia
     else:
         grad_output = grad_output.contiguous()
     rois = rois.contiguous()
+    cl_grad = bool(channels_last_grad) and C % 4 == 0 and path in (PATH_AUTO, PATH_TILED) and R > 0
     with torch.cuda.device_of(grad_output):
-        grad_in = torch.empty((B, C, H, W), dtype=torch.float32, device=grad_output.device)
+        grad_in = torch.empty((B, C, H, W), dtype=torch.float32, device=grad_output.device,
+                              memory_format=torch.channels_last if cl_grad else torch.contiguous_format)
         if grad_in.numel() == 0:
             return grad_in
         nbytes = 0 if path == PATH_DIRECT else _lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, ph, pw)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=grad_output.device)
-        st = _lib.rroi_align_backward_layout_hip(grad_output.data_ptr(), layout, float(spatial_scale), B, R,
-                                                 H, W, C, ph, pw, rois.data_ptr(), grad_in.data_ptr(),
+        st = _lib.rroi_align_backward_layout_hip(grad_output.data_ptr(), layout,
+                                                 LAYOUT_NHWC if cl_grad else LAYOUT_NCHW, float(spatial_scale),
+                                                 B, R, H, W, C, ph, pw, rois.data_ptr(), grad_in.data_ptr(),
                                                  ws.data_ptr(), nbytes, path, _stream())
     _check(st, "rroi_align_backward_hip")
     return grad_in

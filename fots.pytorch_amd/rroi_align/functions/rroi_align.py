@@ -22,6 +22,9 @@ class _RRoiAlignOp(Function):
         ctx.pooled_width = pooled_width
         ctx.spatial_scale = spatial_scale
         ctx.feature_size = features.size()
+        # a channels_last backbone gets its gradient back in channels_last storage
+        ctx.channels_last_grad = (features.dim() == 4 and not features.is_contiguous()
+                                  and features.is_contiguous(memory_format=torch.channels_last))
         ctx.save_for_backward(rois)
         return rroi_align.forward(features, rois, pooled_height, pooled_width, spatial_scale,
                                   channels_last_out=channels_last_out)
@@ -32,8 +35,8 @@ class _RRoiAlignOp(Function):
         (rois,) = ctx.saved_tensors
         grad_input = None
         if ctx.needs_input_grad[0]:
-            grad_input = rroi_align.backward(grad_output, rois, ctx.feature_size,
-                                             ctx.spatial_scale)
+            grad_input = rroi_align.backward(grad_output, rois, ctx.feature_size, ctx.spatial_scale,
+                                             channels_last_grad=ctx.channels_last_grad)
         return grad_input, None, None, None, None, None
 
 

@@ -120,15 +120,17 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
                             float* bottom_diff, void* workspace, size_t workspace_bytes, int path,
                             void* stream);
 
-/* The same with the layout of top_diff stated: RROI_LAYOUT_NCHW (R, C, PH, PW) as above, or
- * RROI_LAYOUT_NHWC = torch channels_last storage (R, PH, PW, C), which the gather formulation
- * consumes in place -- no relayout pass (needs C % 4 == 0; path AUTO or TILED).  This is what
- * autograd hands over when the recognition head runs in channels_last. */
-int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, float spatial_scale,
-                                   int batch_size, int num_rois, int height, int width, int channels,
-                                   int pooled_height, int pooled_width, const float* rois,
-                                   float* bottom_diff, void* workspace, size_t workspace_bytes,
-                                   int path, void* stream);
+/* The same with the layouts stated.  top_diff_layout: RROI_LAYOUT_NCHW (R, C, PH, PW) as above, or
+ * RROI_LAYOUT_NHWC = torch channels_last storage (R, PH, PW, C) -- what autograd hands over when
+ * the recognition head runs in channels_last -- which the gather formulation consumes in place (no
+ * relayout pass).  bottom_diff_layout: NCHW (B, C, H, W) as above, or NHWC storage (B, H, W, C),
+ * written directly (no relayout back) for a channels_last backbone.  Either NHWC needs
+ * C % 4 == 0 and path AUTO or TILED. */
+int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, int bottom_diff_layout,
+                                   float spatial_scale, int batch_size, int num_rois, int height,
+                                   int width, int channels, int pooled_height, int pooled_width,
+                                   const float* rois, float* bottom_diff, void* workspace,
+                                   size_t workspace_bytes, int path, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * 3. The callers' ROI construction, on the device.

@@ -221,8 +221,16 @@ def test_channels_last_pipeline_through_autograd(ext, oracle):
     assert pooled.is_contiguous(memory_format=torch.channels_last)
     assert mismatch(pooled.detach().cpu().numpy(), want)[0] == 0
     pooled.pow(2).sum().backward()          # grad_output = 2 * pooled, channels_last
+    assert feats.grad.is_contiguous(memory_format=torch.channels_last)   # written in place, no relayout
     got = feats.grad.cpu().numpy()
     assert np.abs(got - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max()))
+    # every combination of gradient layouts through the native entry
+    gout = (2 * want).astype(np.float32)
+    for G in (dev(gout), dev(gout).contiguous(memory_format=torch.channels_last)):
+        for cl in (False, True):
+            g = ext.backward(G, dev(r), f.shape, s, channels_last_grad=cl)
+            assert g.is_contiguous(memory_format=torch.channels_last) == cl or g.is_contiguous()
+            assert np.abs(g.cpu().numpy() - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max()))
 
 
 @pytest.mark.parametrize("name", ["mid_c64", "batch3", "train_11xceil"])
@@ -245,7 +253,7 @@ def test_backward_channels_last_grad(ext, oracle, name):
     nb = ext._lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, ph, pw)
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
     gin = torch.empty(f.shape, device="cuda")
-    st = ext._lib.rroi_align_backward_layout_hip(G.data_ptr(), ext.LAYOUT_NHWC, s, B, R, H, W, C, ph, pw,
+    st = ext._lib.rroi_align_backward_layout_hip(G.data_ptr(), ext.LAYOUT_NHWC, ext.LAYOUT_NCHW, s, B, R, H, W, C, ph, pw,
                                                  dev(r).data_ptr(), gin.data_ptr(), ws.data_ptr(), nb,
                                                  ext.PATH_DIRECT, torch.cuda.current_stream().cuda_stream)
     assert st == 0

@@ -42,7 +42,7 @@ g_cl = g.contiguous(memory_format=torch.channels_last)
 
 
 def call_cl():
-    rc = ext._lib.rroi_align_backward_layout_hip(g_cl.data_ptr(), ext.LAYOUT_NHWC, 0.25, B, 512, H, W, C, 8, 64,
+    rc = ext._lib.rroi_align_backward_layout_hip(g_cl.data_ptr(), ext.LAYOUT_NHWC, ext.LAYOUT_NCHW, 0.25, B, 512, H, W, C, 8, 64,
                                                  R.data_ptr(), gin.data_ptr(), ws.data_ptr(), nb, ext.PATH_TILED, st)
     assert rc == 1, rc
 
