@@ -73,8 +73,16 @@ for t in range(trials):
             bad += 1
             print(f"BWD MISMATCH trial {t} path {p}: C={C} {H}x{W} B={B} {ph}x{pw} s={s} R={R}: err {e} scale {sc}")
     if C % 4 == 0:
+        got = ext.forward(F, Rr, ph, pw, s, channels_last_out=True).cpu().numpy()
+        if int((~((got == want) | (np.isnan(got) & np.isnan(want)))).sum()):
+            bad += 1
+            print(f"FWD MISMATCH trial {t} channels_last_out")
         Gcl = G.contiguous(memory_format=torch.channels_last)
-        g = ext.backward(Gcl, Rr, f.shape, s).cpu().numpy()
+        g = ext.backward(G, Rr, f.shape, s, channels_last_grad=True).cpu().numpy()
+        if not float(np.abs(g - gw).max()) <= 1e-4 * sc:
+            bad += 1
+            print(f"BWD MISMATCH trial {t} channels_last_grad")
+        g = ext.backward(Gcl, Rr, f.shape, s, channels_last_grad=bool(t & 1)).cpu().numpy()
         e = float(np.abs(g - gw).max())
         if not e <= 1e-4 * sc:
             bad += 1
