@@ -25,16 +25,17 @@ def rois_from_quads(quads, batch_index=None, training=False, target_h=11):
 class BatchedRRoiAlign(Module):
     """forward(features, quads[, batch_index]) -> (crops (N, C, target_h, max_gw), target_gw (N,))."""
 
-    def __init__(self, target_h=11, spatial_scale=1.0 / 4, pooled_width=None):
+    def __init__(self, target_h=11, spatial_scale=1.0 / 4, pooled_width=None, channels_last_out=False):
         super(BatchedRRoiAlign, self).__init__()
         self.target_h = int(target_h)
         self.spatial_scale = float(spatial_scale)
         self.pooled_width = pooled_width  # fixed width avoids the one-int device->host read
+        self.channels_last_out = bool(channels_last_out)  # crops for a channels_last recognition head
 
     def forward(self, features, quads, batch_index=None):
         rois, gw = rois_from_quads(quads, batch_index, False, self.target_h)
         width = self.pooled_width
         if width is None:
             width = int(gw.max().item()) if gw.numel() else 64
-        crops = _RRoiAlign(self.target_h, width, self.spatial_scale)(features, rois)
+        crops = _RRoiAlign(self.target_h, width, self.spatial_scale, self.channels_last_out)(features, rois)
         return crops, gw

@@ -67,11 +67,11 @@ class ShardedRRoiAlign(Module):
     """
 
     def __init__(self, pooled_height, pooled_width, spatial_scale, group=None, gather=False,
-                 op=None):
+                 op=None, channels_last_out=False):
         super(ShardedRRoiAlign, self).__init__()
         if op is None:
             from .modules.rroi_align import _RRoiAlign
-            op = _RRoiAlign(pooled_height, pooled_width, spatial_scale)
+            op = _RRoiAlign(pooled_height, pooled_width, spatial_scale, channels_last_out)
         self.op = op
         self.group = group
         self.gather = gather
