@@ -28,6 +28,40 @@ def test_header_lists_expected_entry_points():
         assert n in names, names
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 (and as C++) with no torch / HIP types."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "h.c"
+    src.write_text('#include "rroi_align_hip.h"\nint main(void) { return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)],
+                   check=True)
+    if shutil.which("g++"):
+        subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)],
+                       check=True)
+    text = open(os.path.join(inc, "rroi_align_hip.h")).read()
+    assert "hipStream_t stream" not in text and "#include <hip" not in text and "at::Tensor" not in text
+
+
+def test_backward_workspace_and_layout_entry_points_are_host_checked():
+    from rroi_align._ext import rroi_align as ext
+    wb = ext._lib.rroi_align_backward_workspace_bytes
+    n = wb(1, 256, 160, 160, 512, 8, 64)
+    assert n >= 512 * 8 * (8 * 64 + 1) * 128      # the relaid-out top_diff dominates
+    assert wb(1, 256, 160, 160, 512, 0, 64) == 0
+    b = ext._lib.rroi_align_backward_layout_hip
+    # channels-last needs C % 4 == 0 and a tiled path; unknown layouts are refused -- before any launch
+    assert b(None, 1, 0, 0.25, 1, 4, 16, 16, 6, 8, 8, None, None, None, 0, 0, None) == 0
+    assert b(None, 1, 0, 0.25, 1, 4, 16, 16, 8, 8, 8, None, None, None, 0, 1, None) == 0
+    assert b(None, 7, 0, 0.25, 1, 4, 16, 16, 8, 8, 8, None, None, None, 0, 0, None) == 0
+    f = ext._lib.rroi_align_forward_layout_hip
+    assert f(None, 0, 1, 0.25, 1, 4, 16, 16, 6, 8, 8, None, None, None, 0, 0, None) == 0
+    assert f(None, 0, 1, 0.25, 1, 4, 16, 16, 8, 8, 8, None, None, None, 0, 1, None) == 0
+
+
 def test_library_exports_every_declared_symbol():
     from rroi_align._ext import rroi_align as ext
     lib = ctypes.CDLL(ext.LIB_PATH)
