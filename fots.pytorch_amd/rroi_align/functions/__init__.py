@@ -1,0 +1,1 @@
+"""rroi_align.functions -- the autograd surface (see rroi_align.py)."""
