@@ -209,6 +209,44 @@ def test_forward_channels_last_output(ext, oracle, name):
         ext.forward(dev(f), dev(r), ph, pw, s, path=ext.PATH_DIRECT, channels_last_out=True)
 
 
+def test_calls_are_graph_capturable(ext):
+    """No allocation, no synchronisation, no host read-back inside the library: forward and
+    backward can be captured into a HIP graph and replayed."""
+    f, r = Wk.bench_inputs(R=40, C=64, seed=23)
+    F, R = dev(f), dev(r)
+    B, C, H, W = f.shape
+    out = torch.empty((40, C, 8, 64), device="cuda")
+    gin = torch.empty(f.shape, device="cuda")
+    nf = ext._lib.rroi_align_forward_workspace_bytes(B, C, H, W, 40, 0)
+    nb = ext._lib.rroi_align_backward_workspace_bytes(B, C, H, W, 40, 8, 64)
+    wf = torch.empty(nf, dtype=torch.uint8, device="cuda")
+    wb = torch.empty(nb, dtype=torch.uint8, device="cuda")
+
+    def calls():
+        st = torch.cuda.current_stream().cuda_stream
+        assert ext._lib.rroi_align_forward_hip(F.data_ptr(), 0, 0.25, B, 40, H, W, C, 8, 64, R.data_ptr(),
+                                               out.data_ptr(), wf.data_ptr(), nf, ext.PATH_TILED, st) == 1
+        assert ext._lib.rroi_align_backward_hip(out.data_ptr(), 0.25, B, 40, H, W, C, 8, 64, R.data_ptr(),
+                                                gin.data_ptr(), wb.data_ptr(), nb, ext.PATH_TILED, st) == 1
+    calls()
+    torch.cuda.synchronize()
+    want_out, want_gin = out.clone(), gin.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        calls()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        calls()
+    out.zero_()
+    gin.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want_out)
+    assert float((gin - want_gin).abs().max()) <= BWD_RTOL * max(1.0, float(want_gin.abs().max()))
+
+
 def test_channels_last_pipeline_through_autograd(ext, oracle):
     """channels_last features -> channels_last crops -> channels_last gradient, through the module:
     values and gradients equal the NCHW pipeline's (forward bit for bit)."""
