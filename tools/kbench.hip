@@ -8,6 +8,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <time.h>
+#include <unistd.h>
 #include <random>
 #include <string>
 #include <vector>
@@ -184,6 +187,33 @@ __global__ __launch_bounds__(64) void k_atomic(float* __restrict__ dst0, int ite
     }
 }
 
+// ---- XCD-local hand-off primitives (probed for the one-launch forward experiment of round 2,
+// tools/experiments/r02_fused_forward.patch; profiles/r02_fused_experiment.md) ---------------
+// rec[b] = raw XCC id register of block b; cnt[x*32] counts arrivals on XCD x with an L2-scope
+// atomic; every block then polls its XCD's counter (MODE 0: sc1 load, MODE 1: L2 atomic add 0,
+// MODE 2: plain load) until it reaches `expect` or `cap` polls; res[b] = polls used (cap = gave up).
+template <int MODE>
+__global__ __launch_bounds__(64) void k_xcd_probe(unsigned* rec, unsigned* cnt, unsigned* res, unsigned expect, unsigned cap)
+{
+    unsigned raw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(raw));
+    const unsigned x = raw & 7u;
+    if (threadIdx.x == 0) {
+        rec[blockIdx.x] = raw;
+        __hip_atomic_fetch_add(cnt + x * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned spins = 0;
+        for (;;) {
+            unsigned v;
+            if (MODE == 0) v = __hip_atomic_load(cnt + x * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (MODE == 1) v = __hip_atomic_fetch_add(cnt + x * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else v = *(volatile unsigned*)(cnt + x * 32);
+            if (v >= expect || ++spins >= cap) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        res[blockIdx.x] = spins;
+    }
+}
+
 struct Timer {
     hipEvent_t a, b;
     Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
@@ -254,6 +284,35 @@ int main(int argc, char** argv)
             hipLaunchKernelGGL(k_store_tile<1>, dim3(4096), dim3(64), 0, 0, out, 8, 8);
             CK(hipMemsetAsync(out, 0, out_elems * 4, 0));
             CK(hipDeviceSynchronize());
+        }
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "xcd") {
+        const int grid = 3072;
+        unsigned *rec, *cnt, *res;
+        CK(hipMalloc(&rec, grid * 4)); CK(hipMalloc(&cnt, 8 * 128)); CK(hipMalloc(&res, grid * 4));
+        std::vector<unsigned> hrec(grid), hres(grid), hcnt(256);
+        for (int mode = 0; mode < 3; ++mode) {
+            CK(hipMemset(cnt, 0, 8 * 128));
+            if (mode == 0) hipLaunchKernelGGL(k_xcd_probe<0>, dim3(grid), dim3(64), 0, 0, rec, cnt, res, grid / 8, 20000u);
+            if (mode == 1) hipLaunchKernelGGL(k_xcd_probe<1>, dim3(grid), dim3(64), 0, 0, rec, cnt, res, grid / 8, 20000u);
+            if (mode == 2) hipLaunchKernelGGL(k_xcd_probe<2>, dim3(grid), dim3(64), 0, 0, rec, cnt, res, grid / 8, 20000u);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(hrec.data(), rec, grid * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hres.data(), res, grid * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hcnt.data(), cnt, 8 * 128, hipMemcpyDeviceToHost));
+            unsigned mism = 0, gaveup = 0, maxs = 0, ormask = 0, andmask = ~0u;
+            for (int b = 0; b < grid; ++b) {
+                mism += (hrec[b] & 7u) != (unsigned)(b % 8);
+                gaveup += hres[b] >= 20000u;
+                maxs = std::max(maxs, hres[b]);
+                ormask |= hrec[b]; andmask &= hrec[b];
+            }
+            printf("mode %d: xcc != block%%8 in %u of %d blocks; raw id or-mask 0x%x and-mask 0x%x; gave up %u; max polls %u; counts",
+                   mode, mism, grid, ormask, andmask, gaveup, maxs);
+            for (int x = 0; x < 8; ++x) printf(" %u", hcnt[x * 32]);
+            printf("\n");
+            fflush(stdout);
         }
         return 0;
     }
