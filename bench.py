@@ -6,21 +6,31 @@
 One "step" = one forward pass of the hot path (prologue relayout + gather kernel)
 over one batch of synthetic input already resident in HBM:  BASELINE.json
 configs[1]  -- features 1x256x160x160 fp32 (NCHW, the reference contract), 512
-random rotated ROIs, pooled 8x64, spatial_scale 0.25.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) the ROIs of a 512*N set are row-sharded
-512 per rank with no data-path collective (configs[3], weak scaling); the time is
-the max over ranks.
+random rotated ROIs, pooled 8x64, spatial_scale 0.25.  With N > 1 the ROIs of a
+512*N set are row-sharded 512 per rank with no data-path collective (configs[3],
+weak scaling); the time is the max over ranks.  N > 1 runs either under
+torch.distributed.run (one rank per GPU, RANK/LOCAL_RANK/WORLD_SIZE in the
+environment) or, when those are absent, spawns its N ranks itself.
 
-Prints ONE JSON line on rank 0.  `value` = ROIs/s of the whole job (both kernels,
-wall clock of the timed region).  `roofline` is for the dominant kernel
-(rroi_fwd_tiled_kernel), from HIP events recorded around that launch alone in a
-second K-step loop on the same stream.  `cpu_baseline` = the oracle (a C port of
-the reference's per-element semantics; the reference has no runnable CPU path)
-timed on this host's cores -- a reported baseline, not the thing measured.
+Prints ONE JSON line on rank 0.
+  value            ROIs/s of the whole job: K steps after W warm-up steps, wall clock between
+                   barrier + synchronize on both sides, max over ranks.
+  roofline         the dominant kernel (rroi_fwd_tiled_kernel): algorithmic bytes of one launch /
+                   its average duration over a FIXED loop of its own (300 warm-up + 500 timed
+                   back-to-back launches between two HIP events on the launch stream -- independent
+                   of --steps/--warmup; runs BEFORE the timed steps, so those start on warm clocks).
+                   `whole_call_frac` is the same bytes over `ms_per_step` (both launches).
+  cpu_baseline     the oracle (a C port of the reference's per-element semantics; the reference has
+                   no runnable CPU path) timed on this host's cores -- a reported baseline, not the
+                   thing measured.
+  extra            N > 1: the step followed by the RCCL all_gather of the crops into one
+                   preallocated (512*N, 256, 8, 64) buffer (`with_gather_ms`), reported beside the
+                   kernel-only step as SURVEY 8(e) asks.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -31,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "fots.pytorch_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_WARM, KERNEL_TIMED = 300, 500  # the roofline loop, fixed
 
 CFG = dict(R=512, C=256, H=160, W=160, img=640, PH=8, PW=64, scale=0.25)
 
@@ -80,16 +91,47 @@ def cpu_baseline(feats, rois):
     }, touched
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawned(local_rank, world, port, args):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    run(args)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults sized so that the GPU reaches its steady clocks before the timed region
-    # (the first few hundred 70 us steps after idle run ~8 % slower) and the run still ends in < 1 s
+    # defaults sized so that the run ends in well under a minute; the driver passes its own K / W
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    if "WORLD_SIZE" in os.environ:          # launched by torch.distributed.run: one rank per GPU
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            ap.error("--gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ["WORLD_SIZE"]))
+        run(args)
+    elif args.gpus == 1:
+        run(args)
+    else:                                    # self-launch: N ranks of this script, one per GPU
+        one_device = os.environ.get("RROI_BENCH_ONE_DEVICE") == "1"
+        if torch.cuda.device_count() < args.gpus and not one_device:
+            sys.exit("bench.py --gpus %d: only %d GPU(s) visible (RROI_BENCH_ONE_DEVICE=1 runs the "
+                     "multi-rank path on one device as a self-test)" % (args.gpus, torch.cuda.device_count()))
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned, args=(args.gpus, _free_port(), args), nprocs=args.gpus, join=True)
+
+
+def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -110,7 +152,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     from rroi_align._ext import rroi_align as ext  # fails loudly if the HIP library is missing
-    from rroi_align.sharded import shard_bounds
+    from rroi_align.sharded import gather_crops, shard_bounds
 
     c = CFG
     feats_np, rois_all = make_inputs(c["R"] * world, c["C"], c["H"], c["W"], c["img"])
@@ -139,6 +181,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def event_loop(fn, warm, timed):
+        """average duration of `timed` back-to-back calls of fn between two events on the launch stream"""
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(timed):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / timed
+
+    # ---- roofline of the dominant kernel: its own fixed loop (also brings the clocks up) --------
+    launch(ext.STAGE_ALL)
+    gather_ms = event_loop(lambda: launch(ext.STAGE_GATHER), KERNEL_WARM, KERNEL_TIMED)
+    prologue_ms = event_loop(lambda: launch(ext.STAGE_PROLOGUE), 100, 200)
+
+    # ---- the metric: W untimed warm-up steps, then exactly K timed steps --------------------------
     for _ in range(args.warmup):
         launch(ext.STAGE_ALL)
     barrier()
@@ -152,28 +212,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # second loop: HIP events around each launch, same stream, same K
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    for e0, e1, e2 in ev:
-        e0.record()
-        launch(ext.STAGE_PROLOGUE)
-        e1.record()
-        launch(ext.STAGE_GATHER)
-        e2.record()
-    torch.cuda.synchronize()
-    pro_ms = np.array([e0.elapsed_time(e1) for e0, e1, _ in ev])
-    gat_ms = np.array([e1.elapsed_time(e2) for _, e1, e2 in ev])
+    # ---- N > 1, on the side: the step followed by the all_gather of the crops -------------------
+    with_gather_ms = gather_err = None
+    if world > 1:
+        try:
+            full = torch.empty((R * world, c["C"], c["PH"], c["PW"]), dtype=torch.float32, device=dev)
+
+            def step_and_gather():
+                launch(ext.STAGE_ALL)
+                gather_crops(out, R * world, out=full)
+            with torch.no_grad():
+                for _ in range(3):
+                    step_and_gather()
+                barrier()
+                t0 = time.perf_counter()
+                n_g = max(1, min(args.steps, 20))
+                for _ in range(n_g):
+                    step_and_gather()
+                barrier()
+                tg = torch.tensor([(time.perf_counter() - t0) / n_g * 1e3], dtype=torch.float64,
+                                  device="cpu" if one_device else dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            with_gather_ms = float(tg.item())
+            del full
+        except Exception as e:  # a backend that cannot gather device tensors (self-test over gloo)
+            gather_err = repr(e)[:200]
 
     # calibration of the bound on this box: a plain device fill of the same 256 MiB output buffer
-    cal = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
-    for _ in range(10):
-        out.fill_(0.0)
-    cal[0].record()
-    for i in range(40):
-        out.fill_(0.0)
-        cal[i + 1].record()
-    torch.cuda.synchronize()
-    fill_ms = float(np.median([cal[i].elapsed_time(cal[i + 1]) for i in range(40)]))
+    fill_ms = event_loop(lambda: out.fill_(0.0), 10, 40)
     launch(ext.STAGE_ALL)  # leave the real result in `out`
     torch.cuda.synchronize()
 
@@ -191,20 +257,13 @@ def main():
                                                  out.data_ptr(), ws_cl.data_ptr(), nb_cl, ext.PATH_TILED, stream)
             if st != 1:
                 raise RuntimeError(f"rroi_align_forward_hip(NHWC) -> {st}")
-        for _ in range(args.warmup):
-            fwd_cl()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fwd_cl()
-        torch.cuda.synchronize()
-        nhwc_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        nhwc_ms = event_loop(fwd_cl, 100, 300)
         launch(ext.STAGE_ALL)  # leave the NCHW result in `out`
         torch.cuda.synchronize()
         del feats_cl, ws_cl
 
     # configs[2] on the side (not part of `value`): backward w.r.t. the features, same shapes
-    bwd_ms = None
+    bwd_ms = bwd_cl_ms = None
     if world == 1:
         gout = torch.randn_like(out)
         nb_b = ext._lib.rroi_align_backward_workspace_bytes(1, c["C"], c["H"], c["W"], R, c["PH"], c["PW"])
@@ -217,14 +276,7 @@ def main():
                                                   ws_b.data_ptr(), nb_b, ext.PATH_TILED, stream)
             if st != 1:
                 raise RuntimeError(f"rroi_align_backward_hip -> {st}")
-        for _ in range(10):
-            bwd()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(50):
-            bwd()
-        torch.cuda.synchronize()
-        bwd_ms = (time.perf_counter() - t0) / 50 * 1e3
+        bwd_ms = event_loop(bwd, 10, 50)
         gout_cl = gout.contiguous(memory_format=torch.channels_last)  # storage (R, PH, PW, C)
 
         def bwd_cl():
@@ -233,15 +285,17 @@ def main():
                                                          gin.data_ptr(), ws_b.data_ptr(), nb_b, ext.PATH_TILED, stream)
             if st != 1:
                 raise RuntimeError(f"rroi_align_backward_layout_hip -> {st}")
-        for _ in range(10):
-            bwd_cl()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(50):
-            bwd_cl()
-        torch.cuda.synchronize()
-        bwd_cl_ms = (time.perf_counter() - t0) / 50 * 1e3
+        bwd_cl_ms = event_loop(bwd_cl, 10, 50)
         del gout, gout_cl, ws_b, gin
+
+    # configs[4] on the side: the end-to-end inference pipeline (backbone + RoIRotate + CRNN head)
+    e2e = None
+    if world == 1 and os.environ.get("RROI_BENCH_E2E", "1") == "1":
+        try:
+            from fots_e2e.bench_e2e import measure as e2e_measure
+            e2e = e2e_measure(dev)
+        except Exception as e:
+            e2e = {"error": repr(e)[:300]}
 
     if rank != 0:
         if dist is not None:
@@ -258,8 +312,8 @@ def main():
     bytes_out = R * c["C"] * c["PH"] * c["PW"] * 4
     bytes_feat = (touched if touched is not None else c["H"] * c["W"]) * c["C"] * 4
     b_alg = bytes_out + R * 24 + bytes_feat
-    gat_avg = float(gat_ms.mean())
-    achieved = b_alg / (gat_avg * 1e-3) / 1e9
+    achieved = b_alg / (gather_ms * 1e-3) / 1e9
+    fill_gbs = out.numel() * 4 / (fill_ms * 1e-3) / 1e9
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes/launch, if collected
@@ -282,27 +336,36 @@ def main():
                    "parallelism": "roi-shard x%d, no data-path collective" % world},
         "roofline": {"bound": "hbm", "kernel": "rroi_fwd_tiled_kernel", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "whole_call_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "algorithmic_bytes": b_alg,
-                     "kernel_ms": {"avg": round(gat_avg, 5), "p10": round(float(np.percentile(gat_ms, 10)), 5),
-                                   "p50": round(float(np.median(gat_ms)), 5),
-                                   "p90": round(float(np.percentile(gat_ms, 90)), 5)},
-                     "prologue_ms_avg": round(float(pro_ms.mean()), 5),
-                     "calibrated": {"what": "torch fill_ of the 256 MiB output buffer on this GPU (median of 40)",
-                                    "GB/s": round(out.numel() * 4 / (fill_ms * 1e-3) / 1e9, 1),
-                                    "frac_of_it": round(achieved / (out.numel() * 4 / (fill_ms * 1e-3) / 1e9), 4)}},
+                     "kernel_ms": {"avg": round(gather_ms, 5),
+                                   "how": "%d back-to-back launches between two HIP events after %d warm-up "
+                                          "launches (includes the ~1 us launch-to-launch gap the rocprofv3 "
+                                          "kernel trace does not)" % (KERNEL_TIMED, KERNEL_WARM)},
+                     "prologue_ms_avg": round(prologue_ms, 5),
+                     "calibrated": {"what": "torch fill_ of the 256 MiB output buffer on this GPU (40 back-to-back)",
+                                    "GB/s": round(fill_gbs, 1), "frac_of_it": round(achieved / fill_gbs, 4)}},
         "cpu_baseline": cpu,
-        "channels_last_call": None if nhwc_ms is None else {
-            "what": "the same forward call with channels-last feature storage, consumed in place (no relayout); "
-                    "K calls after W warm-up calls; not part of `value` (BASELINE's contract is NCHW)",
-            "ms_per_call": round(nhwc_ms, 5), "ROIs/s": round(R / (nhwc_ms * 1e-3), 1),
-            "frac_of_peak_whole_call": round(b_alg / (nhwc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-        "backward": None if bwd_ms is None else {
-            "what": "configs[2]: grad w.r.t. the features, same shapes, rroi_align_backward_hip (gather path), "
-                    "wall time per call over 50 calls; not part of `value`",
-            "ms_per_call": round(bwd_ms, 5),
-            "ms_per_call_channels_last": round(bwd_cl_ms, 5)},  # top_diff and the feature gradient both in channels_last storage
+        "extra": {
+            "with_gather_ms": None if with_gather_ms is None else round(with_gather_ms, 4),
+            "with_gather": None if world == 1 else (
+                gather_err or "step + all_gather_into_tensor of the crops into one preallocated "
+                              "(%d, 256, 8, 64) buffer (%.2f GiB), max over ranks" % (R * world, R * world * 524288 / 2 ** 30)),
+            "channels_last_call": None if nhwc_ms is None else {
+                "what": "the same forward call with channels-last feature storage, consumed in place (no relayout); "
+                        "not part of `value` (BASELINE's contract is NCHW)",
+                "ms_per_call": round(nhwc_ms, 5), "ROIs/s": round(R / (nhwc_ms * 1e-3), 1),
+                "frac_of_peak_whole_call": round(b_alg / (nhwc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "backward": None if bwd_ms is None else {
+                "what": "configs[2]: grad w.r.t. the features, same shapes, rroi_align_backward_hip (gather path), "
+                        "50 back-to-back calls; not part of `value`",
+                "ms_per_call": round(bwd_ms, 5),
+                "ms_per_call_channels_last": round(bwd_cl_ms, 5)},  # top_diff and the feature gradient both channels_last
+            "e2e": e2e,
+        },
     }
     print(json.dumps(line))
+    sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

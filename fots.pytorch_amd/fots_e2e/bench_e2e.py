@@ -1,0 +1,96 @@
+"""BASELINE configs[4]: images/s of the end-to-end inference pipeline (`test.py:75-116`) on the
+reference's own test images (`data/example_image/*.jpg`, 1280x720 -> 1280x704), random weights
+(the checkpoint is not in the reference's repository), per-box vs batched recognition.
+
+Timed per image, after warm-up, device-synchronised: upload of the decoded uint8 image, resize +
+normalisation, backbone + heads, recognition of the image's boxes (RoIRotate + CRNN head + greedy
+CTC) and the read-back of the strings.  JPEG decoding is done once, outside the timed region.
+Boxes: `synthetic_boxes` (24 per image, seeded) -- with random detection weights the score map
+carries no text regions, so the detector's post-processing is measured on its own (rroi_align.nms).
+"""
+import glob
+import os
+import time
+
+import numpy as np
+import torch
+
+from .alphabet import ALPHABET
+from .model import FOTSNet
+from .pipeline import batched, per_box, preprocess, resize_rule, synthetic_boxes
+from .weights import deterministic_init
+
+BOXES_PER_IMAGE = 24
+
+
+def load_images(limit=None):
+    """Decoded uint8 BGR arrays of the reference's example images (data fixtures under
+    tests/golden/ref_data), or seeded noise of the same size when they are not there."""
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    paths = sorted(glob.glob(os.path.join(root, "tests", "golden", "ref_data", "example_image", "*.jpg")))
+    ims, source = [], "data/example_image/*.jpg (11 images, 1280x720)"
+    try:
+        from PIL import Image
+        for p in paths[:limit]:
+            ims.append(np.ascontiguousarray(np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1]))  # BGR like cv2.imread
+    except Exception:
+        ims = []
+    if not ims:
+        rng = np.random.default_rng(0)
+        ims = [rng.integers(0, 256, (720, 1280, 3), dtype=np.uint8) for _ in range(limit or 11)]
+        source = "seeded noise, 1280x720 (example images not found)"
+    return ims, source
+
+
+def measure(device, reps=3, channels_last=False):
+    from rroi_align.decode import CTCLabelConverter
+    net = deterministic_init(FOTSNet(len(ALPHABET) + 1)).eval().to(device)
+    if channels_last:
+        net = net.to(memory_format=torch.channels_last)
+    conv = CTCLabelConverter(ALPHABET)
+    ims, source = load_images()
+    boxes = []
+    for i, im in enumerate(ims):
+        h, w = resize_rule(im.shape[0], im.shape[1])
+        boxes.append(synthetic_boxes(BOXES_PER_IMAGE, h, w, seed=100 + i))
+
+    def run(recognise, timed):
+        t_net = t_rec = 0.0
+        texts = None
+        for i, im in enumerate(ims):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            im_data = preprocess(im, device)
+            _, _, _, feats = net(im_data)
+            if timed:
+                torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            texts = recognise(net, conv, feats, boxes[i])
+            torch.cuda.synchronize(device)
+            t2 = time.perf_counter()
+            t_net += t1 - t0
+            t_rec += t2 - t1
+        return t_net, t_rec, texts
+
+    out = {}
+    with torch.no_grad():
+        same = None
+        for name, fn in (("per_box", per_box), ("batched", batched)):
+            run(fn, False)  # warm-up: MIOpen picks its kernels for every crop width here
+            best = None
+            for _ in range(reps):
+                t_net, t_rec, texts = run(fn, True)
+                if best is None or t_net + t_rec < best[0] + best[1]:
+                    best = (t_net, t_rec)
+            n = len(ims)
+            out[name] = {"images_per_s": round(n / (best[0] + best[1]), 2),
+                         "backbone_ms_per_image": round(best[0] / n * 1e3, 3),
+                         "recognition_ms_per_image": round(best[1] / n * 1e3, 3)}
+            same = texts if same is None else (same == texts)
+    out["what"] = ("configs[4]: %s -> 1280x704, FOTSNet (ModelResNetSep2 restated, random weights), %d seeded boxes per "
+                   "image, RoIRotate 11 x target_gw on the 64-ch 1/4 map, CRNN head, greedy CTC; best of %d passes over "
+                   "the images; per_box = the reference's loop (R = 1 launch, head and decode per word), batched = one "
+                   "RoIRotate launch per image, head per width bucket" % (source, BOXES_PER_IMAGE, reps))
+    out["last_image_texts_equal"] = bool(same) if isinstance(same, bool) else None
+    out["speedup"] = round(out["batched"]["images_per_s"] / out["per_box"]["images_per_s"], 2)
+    return out

@@ -1,0 +1,130 @@
+"""The inference driver around RoIRotate, restated on PyTorch-ROCm (`test.py:44-127`).
+
+    im (H0, W0, 3) uint8 BGR --resize_rule/preprocess--> im_data (1, 3, H, W) in [-1, 1)
+      --net--> score, rbox, angle maps (1/4) and features [merged 256 ch, focr 64 ch]
+      --boxes--> (N, 9) quads + score   (`nms.get_boxes`; rroi_align.nms here, or a seeded synthetic
+                                          set while the detection heads carry random weights)
+      --recognise--> N strings          two implementations with identical results:
+
+  per_box   the reference's structure, `tools/ocr_utils.py:131-199` per word: ROI built on the host
+            (Python floats), uploaded, `_RRoiAlign(11, target_gw, 1/4)` with R = 1, `forward_ocr`,
+            `max(1)`, `decode`: ~6 launches + 1 upload + 1 read-back per WORD;
+  batched   ROI rows of all boxes built on the device (`rroi_align_quads_to_rois_hip`), ONE RoIRotate
+            launch per image at the widest pooled width, `forward_ocr` once per width BUCKET on the
+            crops' own first target_gw columns (InstanceNorm statistics are per sample and per
+            width, so a word must see exactly the columns the per-box call gives it), one batched
+            greedy-CTC launch per bucket: per IMAGE a handful of launches and one read-back.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from rroi_align.batched import rois_from_quads
+from rroi_align.decode import ctc_greedy_decode
+from rroi_align.modules.rroi_align import _RRoiAlign
+
+TARGET_H = 11           # tools/ocr_utils.py:147
+SPATIAL_SCALE = 1.0 / 4  # :151, features[1] is the 1/4-resolution map
+
+
+def resize_rule(h0, w0, max_size=1585152, scale_up=False):
+    """(resize_h, resize_w) of `resize_image` (test.py:25-41): multiples of 32, area capped."""
+    f = 3 if scale_up else 1
+    size = [w0 * f // 32 * 32, h0 * f // 32 * 32]
+    while size[0] * size[1] > max_size:
+        size[0] /= 1.2
+        size[1] /= 1.2
+        size[0] = int(size[0] // 32) * 32
+        size[1] = int(size[1] // 32) * 32
+    return int(size[1]), int(size[0])
+
+
+def preprocess(im_u8, device):
+    """(H0, W0, 3) uint8 -> (1, 3, H, W) fp32 = resized / 128 - 1 (test.py:77-83).  The resize is
+    half-pixel bilinear like cv2.resize's default, done on the device."""
+    t = torch.as_tensor(im_u8).to(device=device, dtype=torch.float32).permute(2, 0, 1).unsqueeze(0)
+    h, w = resize_rule(t.shape[2], t.shape[3])
+    if (h, w) != tuple(t.shape[2:]):
+        t = F.interpolate(t, size=(h, w), mode="bilinear", align_corners=False)
+    return t / 128 - 1
+
+
+def synthetic_boxes(n, height, width, seed=0):
+    """(n, 9) fp32 [x0,y0,x1,y1,x2,y2,x3,y3,score]: word-shaped rotated rectangles inside a
+    height x width image, corner order as `nms.get_boxes` hands them to `align_ocr` (edge 0->1 is
+    the short side, 1->2 the long one).  Stands in for the detector's output while its heads carry
+    random weights (a random score map passes no box, or a hundred thousand, through the NMS)."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((n, 9), np.float32)
+    for i in range(n):
+        h = rng.uniform(14, 48)
+        w = h * rng.uniform(1.5, 9.0)
+        a = rng.uniform(-25, 25) / 180 * math.pi
+        m = 0.5 * (w + h)
+        cx, cy = rng.uniform(m, max(m + 1, width - m)), rng.uniform(m, max(m + 1, height - m))
+        ux, uy, vx, vy = math.cos(a), math.sin(a), -math.sin(a), math.cos(a)
+        p1 = (cx - ux * w / 2 - vx * h / 2, cy - uy * w / 2 - vy * h / 2)
+        p2 = (p1[0] + ux * w, p1[1] + uy * w)
+        p0 = (p1[0] + vx * h, p1[1] + vy * h)
+        p3 = (p2[0] + vx * h, p2[1] + vy * h)
+        out[i] = (*p0, *p1, *p2, *p3, rng.uniform(0.5, 1.0))
+    return out
+
+
+def host_roi(box):
+    """One box -> ([0, int(cx), int(cy), h, w, angle], target_gw) as `align_ocr` computes them on
+    the host (tools/ocr_utils.py:133-150): numpy fp32 corner arithmetic, Python-float sqrt/atan2."""
+    b = np.asarray(box[0:8], np.float32).reshape(-1, 2)
+    center = (b[0, :] + b[1, :] + b[2, :] + b[3, :]) / 4
+    dw, dh = b[2, :] - b[1, :], b[1, :] - b[0, :]
+    w = math.sqrt(dw[0] * dw[0] + dw[1] * dw[1])
+    h = math.sqrt(dh[0] * dh[0] + dh[1] * dh[1])
+    angle = -math.atan2(b[2][1] - b[1][1], b[2][0] - b[1][0]) / 3.1415926535 * 180
+    gw = int(w * (TARGET_H / max(1, h))) + TARGET_H
+    return [0, int(center[0]), int(center[1]), h, w, angle], max(2, gw // 32) * 32
+
+
+def per_box(net, converter, features, boxes, return_crops=False):
+    """The reference's loop (test.py:102-116): one word at a time.  -> texts[, crops, labels]"""
+    focr = features[1]
+    texts, crops, labels = [], [], []
+    for box in boxes:
+        roi, gw = host_roi(box)
+        rois = torch.tensor(roi).to(torch.float).to(focr.device)
+        x = _RRoiAlign(TARGET_H, gw, SPATIAL_SCALE)(focr, rois.view(-1, 6))
+        logp = net.forward_ocr(x)
+        _, lab = logp.max(1)
+        lab = lab.transpose(1, 0).contiguous().view(-1)
+        texts.append(converter.decode(lab.cpu(), torch.IntTensor([lab.size(0)]), raw=False))
+        if return_crops:
+            crops.append(x)
+            labels.append(lab)
+    return (texts, crops, labels) if return_crops else texts
+
+
+def batched(net, converter, features, boxes, return_crops=False):
+    """All words of an image at once.  `boxes`: (N, >= 8) tensor on the device (or array)."""
+    focr = features[1]
+    quads = torch.as_tensor(boxes, dtype=torch.float32, device=focr.device)[:, :8].contiguous()
+    n = quads.shape[0]
+    if n == 0:
+        return ([], [], []) if return_crops else []
+    rois, gw = rois_from_quads(quads, None, False, TARGET_H)
+    gw_host = gw.cpu()                                  # the one read-back before the head
+    widths = sorted(set(int(v) for v in gw_host))
+    crops_all = _RRoiAlign(TARGET_H, widths[-1], SPATIAL_SCALE)(focr, rois)
+    texts = [None] * n
+    crops, labels = [None] * n, [None] * n
+    for wdt in widths:                                  # buckets are multiples of 32: a handful
+        idx = torch.nonzero(gw_host == wdt).view(-1)
+        x = crops_all[idx.to(focr.device), :, :, :wdt]
+        logp = net.forward_ocr(x)
+        decoded, dlen, lab = ctc_greedy_decode(logp, None, return_labels=True)
+        decoded, dlen = decoded.cpu(), dlen.cpu()
+        for j, i in enumerate(idx.tolist()):
+            texts[i] = converter.to_text(decoded[j, :int(dlen[j])])
+            if return_crops:
+                crops[i], labels[i] = x[j:j + 1], lab[j].to(torch.int64)
+    return (texts, crops, labels) if return_crops else texts

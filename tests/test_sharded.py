@@ -87,3 +87,57 @@ def test_world2_gloo_matches_single_process(oracle, R, gather):
             lo, hi = shard_bounds(R, world, rank)
             assert np.array_equal(out, full[lo:hi])
         assert np.allclose(g, gfull, rtol=1e-5, atol=1e-5)
+
+
+def _grad_worker(rank, world, port, R, reduce_grad, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "fots.pytorch_amd"), os.path.join(root, "tests")]
+    from rroi_align.sharded import ShardedRRoiAlign
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        f = torch.arange(24, dtype=torch.float32).view(1, 2, 3, 4).requires_grad_(True)
+        rois = torch.arange(R * 6, dtype=torch.float32).view(R, 6)
+
+        def op(features, r):  # any differentiable per-row operator
+            return (r[:, 1].view(-1, 1, 1, 1) * features.mean()).expand(-1, 3, 2, 2).contiguous()
+
+        m = ShardedRRoiAlign(2, 2, 1.0, gather=True, op=op, reduce_grad=reduce_grad)
+        crops = m(f, rois)
+        assert crops.requires_grad and crops.shape == (R, 3, 2, 2)
+        ((rank + 1.0) * crops).sum().backward()   # every rank a different loss on ALL crops
+        q.put((rank, crops.detach().numpy(), f.grad.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("R,reduce_grad", [(6, True), (5, True), (6, False)])
+def test_gather_is_differentiable(R, reduce_grad):
+    """the gathered crops used to be detached.  The backward of the gather is its
+    adjoint: rank q's shard receives the sum over ranks of their gradient slice (reduce_grad) or
+    its own slice (replicated loss)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, R, reduce_grad, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        rank, crops, g = q.get(timeout=120)
+        got[rank] = (crops, g)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from rroi_align.sharded import shard_bounds
+    rois = np.arange(R * 6, dtype=np.float32).reshape(R, 6)
+    mean = np.arange(24, dtype=np.float32).mean()
+    full = np.broadcast_to((rois[:, 1] * mean).reshape(-1, 1, 1, 1), (R, 3, 2, 2))
+    for rank in range(world):
+        crops, g = got[rank]
+        assert np.array_equal(crops, full)
+        lo, hi = shard_bounds(R, world, rank)
+        weight = 3.0 if reduce_grad else rank + 1.0          # sum over ranks of (r + 1), or the own one
+        want = weight * rois[lo:hi, 1].sum() * 12 / 24.0    # 12 crop elements per row, mean over 24
+        assert np.allclose(g, want, rtol=1e-6), (rank, g.ravel()[0], want)
