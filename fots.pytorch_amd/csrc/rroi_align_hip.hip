@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "rroi_align_hip.h"
 
 #pragma clang fp contract(off)
@@ -47,23 +49,22 @@ inline int launch_status() { return status_of(hipGetLastError()); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
-struct DeviceShape {
-    int cus = 256;
-    bool init = false;
-};
-DeviceShape g_dev;
+// CU count per device ordinal (a process may drive several GPUs, one per thread or per call):
+// grids are sized for the device that is current at the call.
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_cus[kMaxDevices];
 
 int num_cus()
 {
-    if (!g_dev.init) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess &&
-            p.multiProcessorCount > 0)
-            g_dev.cus = p.multiProcessorCount;
-        g_dev.init = true;
-    }
-    return g_dev.cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    int cus = g_cus[dev].load(std::memory_order_relaxed);
+    if (cus > 0) return cus;
+    cus = 256;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
+    g_cus[dev].store(cus, std::memory_order_relaxed);
+    return cus;
 }
 
 // Row pitch (pixels = 128-byte lines) of the chunk-major copy: W plus a pad that makes the
@@ -85,8 +86,9 @@ bool shape_ok(int batch_size, int num_rois, int height, int width, int channels,
     // tap offsets inside a slice are 32-bit BYTE offsets; the image stride is a 32-bit float count
     const long nchunks = (channels + kChunk - 1) / kChunk;
     const long slice_px = (long)height * (width + 16) + 1;
-    if (slice_px * kLineBytes >= (1L << 31)) return false;                          // chunk-major (< kOOB)
-    if ((long)height * width * channels * 4 >= (1L << 31)) return false;            // channels-last
+    // tap offsets: < kQuadOOB = 2^30, so that (offset or kOOB) + (quad offset or kQuadOOB) never wraps
+    if (slice_px * kLineBytes >= (1L << 30)) return false;                          // chunk-major
+    if ((long)height * width * channels * 4 >= (1L << 30)) return false;            // channels-last
     if ((long)kChunk * pooled_height * pooled_width * 4 >= (1L << 31)) return false; // one output block
     if (slice_px * kChunk * nchunks >= (1L << 32)) return false;                    // img_stride
     if ((long)pooled_height * pooled_width >= (1L << 31)) return false;
@@ -193,8 +195,9 @@ BwdWorkspace carve_bwd(void* ws, int batch_size, int channels, int height, int w
     const size_t pair_bytes = align_up(4 * R * NB * sizeof(uint2), 256);
     const size_t td_bytes = align_up(R * nchunks * ((size_t)NB + 1) * kLineBytes, 256);
     // pair slots, top_diff line indices and keys are 32-bit; the gather launches one thread group per key
+    // ... and its thread index (key * lanes-per-pixel, at most 64) and block index are 32-bit too
     w.gather_ok = 4 * R * NB < (1ull << 32) && R * nchunks * ((size_t)NB + 1) < (1ull << 32) &&
-                  nkeys * 64 < (1ull << 40) && nkeys < (1ull << 31);
+                  nkeys * 64 < (1ull << 32) && nkeys < (1ull << 31);
     char* b = reinterpret_cast<char*>(ws);
     w.aff = reinterpret_cast<Affine*>(b);
     b += aff_bytes;
@@ -345,7 +348,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         direct_grid(num_rois, NB, channels, grid, cslab);
         hipLaunchKernelGGL(rroi_fwd_direct_kernel, grid, dim3(256), 0, stream, features, rois,
                            top_data, (float*)nullptr, (float*)nullptr, num_rois, channels, height,
-                           width, pooled_height, pooled_width, spatial_scale, batch_size, cslab);
+                           width, pooled_height, pooled_width, spatial_scale, batch_size, cslab, 0);
         return launch_status();
     }
 
@@ -658,6 +661,17 @@ int rroi_align_quads_to_rois_hip(const float* quads, const float* batch_index, i
     return launch_status();
 }
 
+int rroi_align_gt_quads_to_rois_hip(const float* quads, const float* batch_index, const float* height_jitter,
+                                    int n, float* rois, float* max_ratio, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n < 0) return 0;
+    if (!max_ratio || (n > 0 && (!quads || !rois))) return 0;
+    hipLaunchKernelGGL(rroi_gt_quads_to_rois_kernel, dim3(1), dim3(256), 0, stream, quads, batch_index,
+                       height_jitter, n, rois, max_ratio);
+    return launch_status();
+}
+
 int rroi_ctc_greedy_decode_hip(const float* logits, int num_seqs, int num_classes, int num_steps,
                                const int* lengths, int* labels, int* decoded, int* decoded_len,
                                void* stream_)
@@ -684,6 +698,10 @@ int rroi_align_sincos_probe_hip(const float* angle_deg, int n, float* out, void*
 }
 
 // ---- the reference's launcher ABI (rroi_align_kernel.h:8-18) ------------------------
+// The signatures carry no workspace (and the forward's no batch count), so the fast paths take
+// their scratch from the stream-ordered allocator: hipMallocAsync / hipFreeAsync on the caller's
+// stream, no synchronisation, nothing outlives the call.  Small problems keep the one-kernel
+// direct paths (no scratch).
 int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
                             const int num_rois, const int height, const int width,
                             const int channels, const int pooled_height, const int pooled_width,
@@ -694,16 +712,49 @@ int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
     if (!shape_ok(1, num_rois, height, width, channels, pooled_height, pooled_width)) return 0;
     if (num_rois == 0) return 1;
     if (!bottom_data || !bottom_rois || !top_data) return 0;
+    if ((con_idx_x == nullptr) != (con_idx_y == nullptr)) return 0;
+    const int NB = pooled_height * pooled_width;
     dim3 grid;
     int cslab;
-    direct_grid(num_rois, pooled_height * pooled_width, channels, grid, cslab);
-    hipLaunchKernelGGL(rroi_fwd_direct_kernel, grid, dim3(256), 0, stream, bottom_data, bottom_rois,
-                       top_data, con_idx_x, con_idx_y, num_rois, channels, height, width,
-                       pooled_height, pooled_width, spatial_scale, /*batch_size unknown*/ -1,
-                       cslab);
-    return launch_status();
+    direct_grid(num_rois, NB, channels, grid, cslab);
+    if (!pick_tiled_fwd(1, channels, height, width, num_rois, NB)) {
+        hipLaunchKernelGGL(rroi_fwd_direct_kernel, grid, dim3(256), 0, stream, bottom_data, bottom_rois,
+                           top_data, con_idx_x, con_idx_y, num_rois, channels, height, width,
+                           pooled_height, pooled_width, spatial_scale, /*batch_size unknown*/ -1,
+                           cslab, 0);
+        return launch_status();
+    }
+    // Tiled path for the ROIs of image 0 (every ROI, in inference and in the benchmark); the
+    // signature does not say how many images `bottom_data` holds, so the ROIs of images >= 1 --
+    // for which the tiled kernels have written zeros -- are then produced by the direct kernel,
+    // which trusts the index as the reference does.  When there are none that launch only reads
+    // the ROI rows.
+    const size_t bytes = carve(nullptr, 1, channels, height, width, num_rois, RROI_LAYOUT_NCHW).bytes;
+    void* ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, bytes, stream);
+    if (e != hipSuccess) return status_of(e);
+    int st = forward_impl(bottom_data, RROI_LAYOUT_NCHW, RROI_LAYOUT_NCHW, spatial_scale, 1, num_rois, height,
+                          width, channels, pooled_height, pooled_width, bottom_rois, top_data, ws, bytes,
+                          RROI_PATH_TILED, RROI_STAGE_ALL, stream_);
+    if (st == 1) {
+        hipLaunchKernelGGL(rroi_fwd_direct_kernel, grid, dim3(256), 0, stream, bottom_data, bottom_rois,
+                           top_data, (float*)nullptr, (float*)nullptr, num_rois, channels, height, width,
+                           pooled_height, pooled_width, spatial_scale, -1, cslab, /*batch_lo*/ 1);
+        st = launch_status();
+    }
+    if (st == 1 && con_idx_x) {
+        hipLaunchKernelGGL(rroi_con_idx_kernel, grid, dim3(256), 0, stream, bottom_rois, con_idx_x, con_idx_y,
+                           num_rois, channels, height, width, pooled_height, pooled_width, spatial_scale, cslab);
+        st = launch_status();
+    }
+    e = hipFreeAsync(ws, stream);
+    return st != 1 ? st : status_of(e);
 }
 
+// con_idx_x / con_idx_y must be the tensors the forward wrote for the same rois (the reference
+// re-reads the bin centres from them, kernel.cu:232-233): the fast path recomputes the centres from
+// the rois instead of reading 2 x (R, C, PH, PW) floats back.  bottom_diff: zero on entry, as the
+// reference requires (functions/rroi_align.py:35) -- the fast path overwrites, the direct path adds.
 int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
                              const int batch_size, const int num_rois, const int height,
                              const int width, const int channels, const int pooled_height,
@@ -711,12 +762,24 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
                              float* bottom_diff, const float* con_idx_x, const float* con_idx_y,
                              void* stream_)
 {
-    (void)spatial_scale;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!shape_ok(batch_size, num_rois, height, width, channels, pooled_height, pooled_width))
         return 0;
     if (num_rois == 0) return 1;
     if (!top_diff || !bottom_rois || !bottom_diff || !con_idx_x || !con_idx_y) return 0;
+    const int NB = pooled_height * pooled_width;
+    if (pick_tiled_bwd(batch_size, channels, height, width, num_rois, NB)) {
+        const size_t bytes = carve_bwd(nullptr, batch_size, channels, height, width, num_rois, NB).bytes;
+        void* ws = nullptr;
+        hipError_t e = hipMallocAsync(&ws, bytes, stream);
+        if (e != hipSuccess) return status_of(e);
+        const int st = rroi_align_backward_layout_hip(top_diff, RROI_LAYOUT_NCHW, RROI_LAYOUT_NCHW, spatial_scale,
+                                                      batch_size, num_rois, height, width, channels, pooled_height,
+                                                      pooled_width, bottom_rois, bottom_diff, ws, bytes,
+                                                      RROI_PATH_TILED, stream_);
+        e = hipFreeAsync(ws, stream);
+        return st != 1 ? st : status_of(e);
+    }
     const long nthreads = (long)num_rois * pooled_height * pooled_width * channels;
     long blocks = (nthreads + 255) / 256;
     const long cap = (long)num_cus() * 32;

@@ -55,6 +55,50 @@ __global__ void rroi_quads_to_rois_kernel(const float* __restrict__ quads, const
     }
 }
 
+// Training side (src/ocr_process.py:196-219, :259-263): the ground-truth quads of a batch -> ROI
+// rows with the caller's height jitter applied where the reference applies it (in double, before
+// the row is rounded to fp32, :204), and the ratio the pooled width is chosen from,
+// max(w / h) over the fp32 rows (:260-262; NaN wins, as torch.max has it).  One block: a training
+// batch has at most a few hundred boxes.
+__global__ __launch_bounds__(256) void rroi_gt_quads_to_rois_kernel(
+    const float* __restrict__ quads, const float* __restrict__ bidx, const float* __restrict__ jitter, int n,
+    float* __restrict__ rois, float* __restrict__ max_ratio)
+{
+    __shared__ float part[256];
+    __shared__ int any_nan;
+    if (threadIdx.x == 0) any_nan = 0;
+    __syncthreads();
+    float best = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float* b = quads + (size_t)i * 8;
+        const double X0 = b[0], Y0 = b[1], X1 = b[2], Y1 = b[3], X2 = b[4], Y2 = b[5], X3 = b[6], Y3 = b[7];
+        const double cx = (((X0 + X1) + X2) + X3) / 4.0, cy = (((Y0 + Y1) + Y2) + Y3) / 4.0;
+        const double dwx = X2 - X1, dwy = Y2 - Y1, dhx = X1 - X0, dhy = Y1 - Y0;
+        const double w = sqrt(dwx * dwx + dwy * dwy);
+        const double h = sqrt(dhx * dhx + dhy * dhy) + (jitter ? (double)jitter[i] : 0.0);
+        double angle = (atan2(Y2 - Y1, X2 - X1) + atan2(Y3 - Y0, X3 - X0)) / 2.0;
+        angle = -angle / 3.1415926535 * 180.0;
+        float* r = rois + (size_t)i * 6;
+        const float hf = (float)h, wf = (float)w;
+        r[0] = bidx ? bidx[i] : 0.0f;
+        r[1] = (float)cx;
+        r[2] = (float)cy;
+        r[3] = hf;
+        r[4] = wf;
+        r[5] = (float)angle;
+        const float ratio = wf / hf;
+        if (ratio != ratio) any_nan = 1;
+        else if (ratio > best) best = ratio;
+    }
+    part[threadIdx.x] = best;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s && part[threadIdx.x + s] > part[threadIdx.x]) part[threadIdx.x] = part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *max_ratio = any_nan ? NAN : part[0];
+}
+
 __global__ void rroi_bin_centres_kernel(const float* __restrict__ rois, float* __restrict__ geom,
                                         int num_rois, int height, int width, int pooled_height,
                                         int pooled_width, float spatial_scale)

@@ -214,7 +214,8 @@ struct SliceLayout {
 // quad beyond C and a bin beyond PH*PW are all just "offset = kOOB".  The hot loop therefore
 // has no branches and no exec masking, and the compiler's s_waitcnt counts are exact.
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
-constexpr unsigned kOOB = 0x80000000u;          // > any slice / tile size (shape_ok: < 2 GiB)
+constexpr unsigned kOOB = 0x80000000u;          // > any slice / tile size (shape_ok)
+constexpr unsigned kQuadOOB = 0x40000000u;      // "this lane's channel quad is beyond C": slices are < 1 GiB
 constexpr unsigned kRsrcWord3 = 0x00020000u;    // raw buffer, 32-bit data format (gfx9 family)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes)

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     // measured 43 vs 16 TCP accesses per load instruction.)
     const unsigned q = lane & (kQuads - 1), b = lane >> 3;
     // a channel quad wholly beyond C never loads (its rows are not stored either)
-    const unsigned q_bytes = ((dbg & 2) || k * kChunk + q * 4 >= (unsigned)C) ? kOOB : q * 16u;
+    const unsigned q_bytes = ((dbg & 2) || k * kChunk + q * 4 >= (unsigned)C) ? kQuadOOB : q * 16u;
     // LDS tile: row r = channel, 68-dword pitch; the column of rows 8m..8m+7 is XORed with
     // 4*m so that the 32 lanes of a store group (8 quads x 4 bins) spread over the banks
     // while rows stay 16-byte aligned for the ds_read_b128 of phase C.
@@ -294,7 +294,8 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         hpos[s] = HPbuf[p * kRecs + grp * kBinsPerIter + b];
     };
     auto issue_lo = [&](__amdgpu_buffer_rsrc_t rs, int s) {
-        // kOOB + q_bytes (or anything + kOOB) stays out of range: no wrap below 2^32
+        // offsets are < 2^30 or kOOB = 2^31, q_bytes is < 128 or kQuadOOB = 2^30: every sum with an
+        // out-of-range term lies in [2^30, 2^32) -- beyond any slice (shape_ok), and it cannot wrap
         lt[s] = buf_load(rs, ra[s].x + q_bytes);
         rt[s] = buf_load(rs, ra[s].y + q_bytes);  // the bin's one other distinct tap, if any
     };
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
     const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
     float* __restrict__ idx_x, float* __restrict__ idx_y, int num_rois, int C, int height,
     int width, int pooled_height, int pooled_width, float spatial_scale, int batch_size,
-    int cslab)
+    int cslab, int batch_lo)
 {
     const int NB = pooled_height * pooled_width;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -535,6 +536,9 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
     const int ph = bin / pooled_width, pw = bin - ph * pooled_width;
 
     const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+    // batch_lo > 0 (reference-ABI launcher): only the ROIs of images >= batch_lo -- the tiled
+    // kernels have already written the others
+    if (A.batch < batch_lo) return;
     float bcx, bcy;
     const bool in_rroi = bin_centre(A, ph, pw, height, width, bcx, bcy);
     // batch_size < 0: unknown (reference ABI) -> trust the index like the reference does
@@ -566,6 +570,32 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
         out[o] = v;
         if (idx_x) idx_x[o] = active ? bcx : 0.0f;
         if (idx_y) idx_y[o] = active ? bcy : 0.0f;
+    }
+}
+
+// con_idx_x / con_idx_y of the reference ABI (kernel.cu:144-145): the bin centre of (roi, ph, pw)
+// replicated over the C channels, 0 where the bin is masked.  thread = (roi, bin), loops a channel
+// slab; consecutive lanes write consecutive bins.
+__global__ __launch_bounds__(256) void rroi_con_idx_kernel(
+    const float* __restrict__ rois, float* __restrict__ idx_x, float* __restrict__ idx_y, int num_rois, int C,
+    int height, int width, int pooled_height, int pooled_width, float spatial_scale, int cslab)
+{
+    const int NB = pooled_height * pooled_width;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)num_rois * NB) return;
+    const int n = (int)(gid / NB);
+    const int bin = (int)(gid - (long)n * NB);
+    const int ph = bin / pooled_width, pw = bin - ph * pooled_width;
+    const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+    float bcx, bcy;
+    const bool in_rroi = bin_centre(A, ph, pw, height, width, bcx, bcy);
+    const float vx = in_rroi ? bcx : 0.0f, vy = in_rroi ? bcy : 0.0f;
+    const int c_begin = blockIdx.y * cslab;
+    const int c_end = min(C, c_begin + cslab);
+    size_t o = ((size_t)n * C + c_begin) * NB + bin;
+    for (int c = c_begin; c < c_end; ++c, o += NB) {
+        __builtin_nontemporal_store(vx, idx_x + o);
+        __builtin_nontemporal_store(vy, idx_y + o);
     }
 }
 

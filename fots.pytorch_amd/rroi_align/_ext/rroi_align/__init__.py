@@ -53,6 +53,8 @@ _lib.rroi_align_bin_centres_hip.restype = _i
 _lib.rroi_align_bin_centres_hip.argtypes = [_f, _i, _i, _i, _i, _i, _vp, _vp, _vp]
 _lib.rroi_align_quads_to_rois_hip.restype = _i
 _lib.rroi_align_quads_to_rois_hip.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]
+_lib.rroi_align_gt_quads_to_rois_hip.restype = _i
+_lib.rroi_align_gt_quads_to_rois_hip.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp]
 _lib.rroi_ctc_greedy_decode_hip.restype = _i
 _lib.rroi_ctc_greedy_decode_hip.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.rroi_align_sincos_probe_hip.restype = _i
@@ -68,6 +70,7 @@ EXPORTS = (
     "rroi_align_backward_workspace_bytes", "rroi_align_bin_centres_hip",
     "rroi_align_sincos_probe_hip", "rroi_align_quads_to_rois_hip", "rroi_align_hip_version",
     "rroi_ctc_greedy_decode_hip", "rroi_align_backward_layout_hip", "rroi_align_forward_layout_hip",
+    "rroi_align_gt_quads_to_rois_hip",
 )
 
 
@@ -240,6 +243,31 @@ def quads_to_rois(quads: torch.Tensor, batch_index=None, mode: int = 0, target_h
                                                _stream())
     _check(st, "rroi_align_quads_to_rois_hip")
     return rois, gw
+
+
+def gt_quads_to_rois(quads: torch.Tensor, batch_index=None, height_jitter=None):
+    """(N, 8) ground-truth quads -> ((N, 6) rois, (1,) max w/h over the fp32 rows), on the device
+    (src/ocr_process.py:196-219, :259-263)."""
+    _require_cuda_f32(quads, "quads")
+    quads = quads.contiguous().view(-1, 8)
+    n = quads.size(0)
+    aux = []
+    for t, name in ((batch_index, "batch_index"), (height_jitter, "height_jitter")):
+        if t is not None:
+            _require_cuda_f32(t, name)
+            t = t.contiguous().view(-1)
+            if t.numel() != n:
+                raise ValueError(f"{name} must have one entry per quad")
+        aux.append(t)
+    with torch.cuda.device_of(quads):
+        rois = torch.empty((n, 6), dtype=torch.float32, device=quads.device)
+        ratio = torch.empty((1,), dtype=torch.float32, device=quads.device)
+        st = _lib.rroi_align_gt_quads_to_rois_hip(quads.data_ptr(),
+                                                  aux[0].data_ptr() if aux[0] is not None else None,
+                                                  aux[1].data_ptr() if aux[1] is not None else None,
+                                                  n, rois.data_ptr(), ratio.data_ptr(), _stream())
+    _check(st, "rroi_align_gt_quads_to_rois_hip")
+    return rois, ratio
 
 
 def sincos_probe(angle_deg: torch.Tensor) -> torch.Tensor:

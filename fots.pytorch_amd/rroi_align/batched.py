@@ -39,3 +39,36 @@ class BatchedRRoiAlign(Module):
             width = int(gw.max().item()) if gw.numel() else 64
         crops = _RRoiAlign(self.target_h, width, self.spatial_scale, self.channels_last_out)(features, rois)
         return crops, gw
+
+
+class GroundTruthRRoiAlign(Module):
+    """The training caller's call (src/ocr_process.py:196-221, :253-267): ground-truth quads of a
+    batch -> crops for the recognition loss, ROI rows and pooled width computed on the device.
+
+    forward(features, quads, batch_index, height_jitter=None) -> (crops (N, C, pooled_height, pooled_width), rois)
+    with pooled_width = ceil(pooled_height * max(w / h)) (:260-263) read back once, as the
+    reference does with `.item()`.  `height_jitter` is the caller's random.randint(-2, 2) (:204), one
+    value per box (the reference draws one per image).  Rows whose jittered h is negative yield
+    all-zero crops (the op's `pw <= roi_pooled_width` mask is false everywhere, kernel.cu:107); an
+    h of exactly 0 makes the ratio infinite -- the reference's `math.ceil` raises there, and so does
+    this module.  The reference truncates to the first 32 rows (:253-255): `max_rois`.
+    """
+
+    def __init__(self, pooled_height=11, spatial_scale=1.0 / 4, max_rois=32):
+        super(GroundTruthRRoiAlign, self).__init__()
+        self.pooled_height = int(pooled_height)
+        self.spatial_scale = float(spatial_scale)
+        self.max_rois = max_rois
+
+    def forward(self, features, quads, batch_index=None, height_jitter=None):
+        import math
+        if self.max_rois is not None:
+            quads = quads[: self.max_rois]
+            batch_index = None if batch_index is None else batch_index[: self.max_rois]
+            height_jitter = None if height_jitter is None else height_jitter[: self.max_rois]
+        rois, ratio = _ext.gt_quads_to_rois(quads, batch_index, height_jitter)
+        r = float(ratio.item())
+        if not math.isfinite(r):
+            raise ValueError("degenerate ground-truth box: max(w / h) is %r (a jittered height of 0, or NaN)" % r)
+        pooled_width = max(1, math.ceil(self.pooled_height * r))
+        return _RRoiAlign(self.pooled_height, pooled_width, self.spatial_scale)(features, rois), rois

@@ -144,6 +144,17 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
 int rroi_align_quads_to_rois_hip(const float* quads, const float* batch_index, int n, int mode,
                                  int target_h, float* rois, int* target_gw, void* stream);
 
+/* The training caller's side, src/ocr_process.py:196-219 and :259-263: ground-truth quads (n, 8)
+ * -> rois (n, 6) with the reference's double-precision arithmetic, `height_jitter` (n) -- the
+ * integer the caller draws with random.randint(-2, 2), :204; NULL = 0 -- added to h in double
+ * before the row is rounded to fp32, and *max_ratio = max over the fp32 rows of w / h (NaN if any
+ * ratio is NaN; -inf for n = 0): pooled_width = ceil(pooled_height * max_ratio), :260-263.  One
+ * launch for the whole batch; a jitter that makes h <= 0 yields the degenerate rows the op handles
+ * as the reference does (h < 0: zeros; h == 0: an infinite ratio, at which the reference's own
+ * math.ceil raises). */
+int rroi_align_gt_quads_to_rois_hip(const float* quads, const float* batch_index, const float* height_jitter,
+                                    int n, float* rois, float* max_ratio, void* stream);
+
 /* Greedy CTC decode of the recognition logits computed from the crops: replaces the per-box
  * `labels_pred.max(1)` + Python loop of tools/ocr_utils.py:183-186 / src/utils.py:87-97
  * (strLabelConverter.decode, raw=False) for all boxes of an image in one launch.

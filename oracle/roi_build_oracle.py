@@ -23,8 +23,9 @@ import math
 import numpy as np
 
 
-def rois_from_quads(quads, batch_idx=None, mode=0, target_h=11):
-    """quads (N, 8) fp32 [x0,y0,...,x3,y3] -> (rois (N,6) fp32, target_gw (N,) int32)."""
+def rois_from_quads(quads, batch_idx=None, mode=0, target_h=11, jitter=None):
+    """quads (N, 8) fp32 [x0,y0,...,x3,y3] -> (rois (N,6) fp32, target_gw (N,) int32).
+    jitter (mode 1): the caller's random.randint(-2, 2) of ocr_process.py:204, scalar or per box."""
     q = np.ascontiguousarray(quads, np.float32).reshape(-1, 4, 2)
     n = q.shape[0]
     bidx = np.zeros(n, np.float32) if batch_idx is None else np.asarray(batch_idx, np.float32)
@@ -45,7 +46,9 @@ def rois_from_quads(quads, batch_idx=None, mode=0, target_h=11):
             center = (d[0] + d[1] + d[2] + d[3]) / 4                       # ocr_process.py:198
             dw, dh = d[2] - d[1], d[1] - d[0]                              # :199-200
             w = math.sqrt(dw[0] ** 2 + dw[1] ** 2)                         # :201-203
-            h = math.sqrt(dh[0] ** 2 + dh[1] ** 2)                         # :204 (jitter is the caller's)
+            h = math.sqrt(dh[0] ** 2 + dh[1] ** 2)                         # :204
+            if jitter is not None:
+                h = h + float(np.broadcast_to(np.asarray(jitter, np.float64), (n,))[i])  # + random.randint(-2, 2)
             angle = (math.atan2(d[2][1] - d[1][1], d[2][0] - d[1][0]) +
                      math.atan2(d[3][1] - d[0][1], d[3][0] - d[0][0])) / 2  # :205
             angle = -angle / 3.1415926535 * 180                            # :206

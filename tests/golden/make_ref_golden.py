@@ -1,5 +1,9 @@
-"""Run the REFERENCE's own kernels (oracle/_ref/librroi_ref_hip.so = rroi_align_kernel.cu through
-ROCm's hipify-perl + hipcc, see oracle/Makefile) on an MI355X and freeze their outputs:
+"""Run the REFERENCE's own kernels (oracle/_ref/librroi_ref_hip_nofma.so = rroi_align_kernel.cu through
+ROCm's hipify-perl + hipcc with -ffp-contract=off, i.e. the SOURCE semantics the oracle and the
+product implement; see oracle/Makefile) on an MI355X and freeze their outputs.  The same sources
+built with the compiler's default FMA contraction (librroi_ref_hip.so -- what nvcc's default
+-fmad=true did to the shipped binary) run next to it: `out_fma_diff` records the output elements at
+which the two builds differ (rounding ties flipped by contraction), so that drift stays visible:
 
     gpurun -- 'python tests/golden/make_ref_golden.py'      # writes gpurun_out/refhip_*.npz
     cp gpurun_out/refhip_*.npz tests/golden/
@@ -20,10 +24,18 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import workloads as Wk  # noqa: E402
 
-ref = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "librroi_ref_hip.so"))
 vp, fl, it = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
-ref.RROIAlignForwardLaucher.argtypes = [vp, fl, it, it, it, it, it, it, vp, vp, vp, vp, vp]
-ref.RROIAlignBackwardLaucher.argtypes = [vp, fl, it, it, it, it, it, it, it, vp, vp, vp, vp, vp]
+
+
+def _load(name):
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", name))
+    lib.RROIAlignForwardLaucher.argtypes = [vp, fl, it, it, it, it, it, it, vp, vp, vp, vp, vp]
+    lib.RROIAlignBackwardLaucher.argtypes = [vp, fl, it, it, it, it, it, it, it, vp, vp, vp, vp, vp]
+    return lib
+
+
+ref = _load("librroi_ref_hip_nofma.so")
+ref_fma = _load("librroi_ref_hip.so")
 
 
 def run(name, feats, rois, ph, pw, scale):
@@ -38,14 +50,23 @@ def run(name, feats, rois, ph, pw, scale):
     gin = torch.zeros_like(F)
     ref.RROIAlignBackwardLaucher(gout.data_ptr(), scale, B, n, H, W, C, ph, pw, R.data_ptr(),
                                  gin.data_ptr(), ix.data_ptr(), iy.data_ptr(), st)
+    out_f, ix_f, iy_f = (torch.zeros((n, C, ph, pw), device="cuda") for _ in range(3))
+    ref_fma.RROIAlignForwardLaucher(F.data_ptr(), scale, n, H, W, C, ph, pw, R.data_ptr(), out_f.data_ptr(),
+                                    ix_f.data_ptr(), iy_f.data_ptr(), st)
     torch.cuda.synchronize()
+    # flat indices (into the (n, ph, pw) bin grid) of the bins whose centre the contracted build moves
+    moved = ((ix_f[:, 0] != ix[:, 0]) | (iy_f[:, 0] != iy[:, 0])).flatten().nonzero().flatten().cpu().numpy()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.savez_compressed(os.path.join(ROOT, "gpurun_out", name), features=feats, rois=rois,
                         pooled=np.asarray([ph, pw], np.int32), scale=np.float32(scale),
                         out=out.cpu().numpy(), idx_x=ix[:, 0].cpu().numpy(), idx_y=iy[:, 0].cpu().numpy(),
                         idx_same_over_channels=bool((ix == ix[:, :1]).all() and (iy == iy[:, :1]).all()),
-                        grad_in=gin.cpu().numpy())
-    print(name, tuple(out.shape), "nonzero", float((out != 0).float().mean()))
+                        grad_in=gin.cpu().numpy(), fma_moved_bins=moved.astype(np.int64),
+                        fma_idx_x=ix_f[:, 0].flatten()[moved].cpu().numpy(),
+                        fma_idx_y=iy_f[:, 0].flatten()[moved].cpu().numpy(),
+                        fma_out_diff=int((torch.nan_to_num(out_f) != torch.nan_to_num(out)).sum()))
+    print(name, tuple(out.shape), "nonzero", float((out != 0).float().mean()), "bins moved by contraction:",
+          len(moved), "of", n * ph * pw)
 
 
 if __name__ == "__main__":
@@ -58,3 +79,5 @@ if __name__ == "__main__":
     run("refhip_edge.npz", f, Wk.edge_rois(), 8, 64, 0.25)
     f, r = Wk.bench_inputs(R=16, C=3, H=90, W=120, img=480, seed=5)
     run("refhip_ph11.npz", f, r, 11, 77, 0.25)
+    f = rng.standard_normal((1, 2, 160, 160), dtype=np.float32)
+    run("refhip_ties.npz", f, Wk.tie_rois(), 8, 64, 0.25)

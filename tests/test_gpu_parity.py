@@ -364,6 +364,42 @@ def test_reference_ffi_names(ext, oracle):
     assert ext.rroi_align_forward_cuda(8, 64, 0.25, F, Rr[:, :5].contiguous(), out, ix, iy) == 0
 
 
+def test_reference_launchers_take_the_fast_paths(ext, oracle):
+    """behind the reference's own symbols (`RROIAlignForwardLaucher` /
+    `RROIAlignBackwardLaucher`, rroi_align_kernel.h:8-18) a large problem runs the tiled forward and
+    the gather backward on stream-ordered scratch; ROIs of images >= 1 (the signature carries no
+    batch count) and con_idx_x / con_idx_y are still produced.  Same results as the literal forms."""
+    f, r = Wk.bench_inputs(R=96, C=64, seed=21, batch=2)   # 3.1 M output elements: above both crossovers
+    assert set(r[:, 0]) == {0.0, 1.0}
+    F, Rr = dev(f), dev(r)
+    shape = (96, 64, 8, 64)
+    out, ix, iy = (torch.full(shape, 7.0, device="cuda") for _ in range(3))
+    assert ext.rroi_align_forward_cuda(8, 64, 0.25, F, Rr, out, ix, iy) == 1
+    want, wx, wy = oracle.forward_literal_c(f, r, 8, 64, 0.25)
+    assert eq(out.cpu().numpy(), want) and eq(ix.cpu().numpy(), wx) and eq(iy.cpu().numpy(), wy)
+    gin = torch.zeros(f.shape, device="cuda")
+    assert ext.rroi_align_backward_cuda(8, 64, 0.25, out * 2, Rr, gin, ix, iy) == 1
+    wb = oracle.backward_literal_c((2 * want).astype(np.float32), r, wx, wy, f.shape, 0.25)
+    assert np.abs(gin.cpu().numpy() - wb).max() <= BWD_RTOL * max(1.0, float(np.abs(wb).max()))
+    # the launcher itself without con_idx (NULL is allowed): the whole call is the two tiled launches
+    st = ext._lib.RROIAlignForwardLaucher(F.data_ptr(), 0.25, 96, 160, 160, 64, 8, 64, Rr.data_ptr(),
+                                          out.fill_(3.0).data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+    assert st == 1 and eq(out.cpu().numpy(), want)
+
+
+def test_channels_last_odd_chunk(ext, oracle):
+    """C % 32 != 0 with channels-last features consumed in place -- the lanes of the
+    channel quads beyond C must fetch nothing (their offset is an out-of-range sentinel that may not
+    wrap when it meets an invalid tap's sentinel)."""
+    for C in (36, 100):
+        f, r = Wk.bench_inputs(R=24, C=C, seed=31 + C, batch=2)
+        r = np.concatenate([r, Wk.edge_rois()[:12]], 0)
+        want = oracle.forward_c(f, r, 8, 64, 0.25, threads=8)
+        cl = dev(f).contiguous(memory_format=torch.channels_last)
+        assert eq(ext.forward(cl, dev(r), 8, 64, 0.25, path=ext.PATH_TILED).cpu().numpy(), want)
+        assert eq(ext.forward(dev(f), dev(r), 8, 64, 0.25, path=ext.PATH_TILED).cpu().numpy(), want)
+
+
 def test_channels_last_is_consumed_in_place(ext, oracle):
     f, r = Wk.bench_inputs(R=20, C=64, seed=15, batch=2)
     want = oracle.forward_c(f, r, 8, 64, 0.25, threads=8)

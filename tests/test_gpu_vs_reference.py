@@ -21,7 +21,10 @@ REFDIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
 def _load(name):
     path = os.path.join(REFDIR, name)
     if not os.path.exists(path):
-        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+        if os.path.isdir("/root/reference"):
+            pytest.fail("oracle/_ref is not built although /root/reference is here: run `make -C oracle ref` "
+                        "(__graft_entry__.build() does)")
+        pytest.skip("oracle/_ref not built (it is built where /root/reference exists and travels as a binary)")
     lib = ctypes.CDLL(path)
     vp, fl, it = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
     lib.RROIAlignForwardLaucher.argtypes = [vp, fl, it, it, it, it, it, it, vp, vp, vp, vp, vp]

@@ -72,3 +72,18 @@ def degenerate_rois():
         [0, 1e30, 320, 20, 100, 10],
         [0, 320, 320, 1e-30, 1e30, 10],
     ], np.float32)
+
+
+def tie_rois(img=640):
+    """Rounding-tie stress (SURVEY.md 8c fixture 3): with h = 32, w = 256, pooled 8x64 and scale 0.25 the
+    affine has unit steps (Sx = Sy = 1), so at 0 / 90 / 180 / -90 degrees and centres on the integer or
+    half-integer grid of the map every bin corner is an exact integer or half-integer: round() sits
+    on ties in every bin, and one ulp in the affine (e.g. from FMA contraction) flips the sample."""
+    rows = []
+    for ang in (0.0, 90.0, 180.0, -90.0, 45.0, -45.0, 30.0):
+        for cx, cy in ((320, 320), (322, 318), (321, 321), (320.5, 320.5), (323, 320), (200, 440), (50, 50), (600, 30)):
+            rows.append([0, cx, cy, 32, 256, ang])
+    for h, w in ((16, 128), (64, 512), (24, 192), (40, 200)):
+        rows.append([0, 320, 320, h, w, 0.0])
+        rows.append([0, 320, 320, h, w, 90.0])
+    return np.asarray(rows, np.float32)
