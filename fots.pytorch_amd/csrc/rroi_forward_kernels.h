@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
     const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
     // batch_lo > 0 (reference-ABI launcher): only the ROIs of images >= batch_lo -- the tiled
     // kernels have already written the others
-    if (A.batch < batch_lo) return;
+    if (batch_lo > 0 && A.batch < batch_lo) return;
     float bcx, bcy;
     const bool in_rroi = bin_centre(A, ph, pw, height, width, bcx, bcy);
     // batch_size < 0: unknown (reference ABI) -> trust the index like the reference does
