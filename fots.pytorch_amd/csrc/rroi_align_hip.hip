@@ -21,14 +21,18 @@
 // by blocks with blockIdx % nchunks == k, i.e. (8 chunks at C=256) by one XCD,
 // whose 4 MiB L2 then holds exactly its 3.2 MB slice of the map.
 //
-// Files: this one holds the host side and the C-ABI; the device code is in four parts that are
+// Files: this one holds the host side and the C-ABI; the device code is in parts that are
 // included below, inside the anonymous namespace: rroi_device_common.h (constants, geometry
 // recipe, descriptor helpers), rroi_forward_kernels.h, rroi_backward_kernels.h,
-// rroi_callers_kernels.h.
+// rroi_callers_kernels.h, rroi_nms_kernels.h (+ rroi_nms_host.h, host C++).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <math.h>
+
+#include <algorithm>
 #include <atomic>
+#include <vector>
 
 #include "rroi_align_hip.h"
 
@@ -40,6 +44,8 @@ namespace {
 #include "rroi_forward_kernels.h"
 #include "rroi_backward_kernels.h"
 #include "rroi_callers_kernels.h"
+#include "rroi_nms_kernels.h"
+#include "rroi_nms_host.h"
 
 // ------------------------------------------------------------------------------------
 // host side
@@ -670,6 +676,38 @@ int rroi_align_gt_quads_to_rois_hip(const float* quads, const float* batch_index
     hipLaunchKernelGGL(rroi_gt_quads_to_rois_kernel, dim3(1), dim3(256), 0, stream, quads, batch_index,
                        height_jitter, n, rois, max_ratio);
     return launch_status();
+}
+
+int rroi_rbox_decode_hip(const float* segm, const float* rbox, const float* angle, int height, int width,
+                         float segm_thresh, void* candidates, int capacity, int* count, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (height <= 0 || width <= 0 || capacity < 0 || (long)height * width >= (1L << 30)) return 0;
+    if (!segm || !rbox || !angle || !count || (capacity > 0 && !candidates)) return 0;
+    hipLaunchKernelGGL(rroi_rbox_decode_kernel, dim3(1), dim3(1024), 0, stream, segm, rbox, angle, height, width,
+                       segm_thresh, static_cast<NmsCandidate*>(candidates), capacity, count);
+    return launch_status();
+}
+
+int rroi_nms_merge_host(const void* candidates, int num_candidates, int width, int height, float iou_threshold,
+                        float iou_threshold2, float* boxes, int max_boxes)
+{
+    if (num_candidates < 0 || width <= 0 || height <= 0 || max_boxes < 0) return -1;
+    if (num_candidates > 0 && !candidates) return -1;
+    const NmsCandidate* cand = static_cast<const NmsCandidate*>(candidates);
+    for (int i = 0; i < num_candidates; ++i)
+        if (cand[i].x < 0 || cand[i].x >= width || cand[i].y < 0 || cand[i].y >= height) return -1;
+    const std::vector<NmsPoly> out = nms_merge(cand, num_candidates, width, height, iou_threshold, iou_threshold2);
+    const int n = (int)out.size();
+    for (int i = 0; i < n && i < max_boxes; ++i) {
+        float* b = boxes + (size_t)i * 9;
+        for (int v = 0; v < 4; ++v) {  // adaptor.cpp:14-31 (float of the integers), nms/__init__.py:15-16 (/ 10000)
+            b[2 * v] = (float)out[(size_t)i].X[v] / 10000.0f;
+            b[2 * v + 1] = (float)out[(size_t)i].Y[v] / 10000.0f;
+        }
+        b[8] = out[(size_t)i].score;
+    }
+    return n;
 }
 
 int rroi_ctc_greedy_decode_hip(const float* logits, int num_seqs, int num_classes, int num_steps,

@@ -1,0 +1,89 @@
+// rroi_nms_kernels.h -- detection post-processing, device part: RBOX decode + threshold + ordered compaction
+// Part of the single translation unit rroi_align_hip.hip (included inside its anonymous namespace
+// after rroi_callers_kernels.h); not a standalone header.
+#pragma once
+
+// ------------------------------------------------------------------------------------
+// the step right before ROI construction.  The reference copies three
+// full-resolution maps to the host (test.py:86-93), transposes them with numpy and walks every
+// pixel in C++ (nms/adaptor.cpp:76-117) before the locality-aware merge (nms/nms.h:149-213).
+// Here the per-pixel part runs where the maps are: every pixel whose score passes the threshold
+// becomes one 64-byte candidate record -- the quad in 1/10000 px integers, the score, the four
+// corner confidences, the pixel -- written in RASTER ORDER (the merge depends on it), and only
+// those records cross to the host.  Channels-first inputs, as the network emits them: no transposes.
+//
+// One workgroup walks the map 1024 pixels at a time and carries the running count: the map is
+// small (176 x 320 at 1280 x 704) and the order is free that way.
+// fp32 arithmetic exactly as adaptor.cpp writes it (-ffp-contract=off); the corner confidences
+// use exp in double rounded once, the C library's expf the reference calls agrees with that except
+// for an occasional last place (the quads do not depend on it).
+// ------------------------------------------------------------------------------------
+struct NmsCandidate {  // 64 bytes
+    int quad[8];       // x0,y0 .. x3,y3 in 1/10000 px (adaptor.cpp:101-104)
+    float score;
+    float probs[4];    // p_left*p_bt, p_left*p_top, p_right*p_top, p_right*p_bt (:107)
+    int x, y;
+    int pad;
+};
+static_assert(sizeof(NmsCandidate) == 64, "one candidate = one 64-byte record");
+
+__global__ __launch_bounds__(1024) void rroi_rbox_decode_kernel(
+    const float* __restrict__ segm, const float* __restrict__ rbox, const float* __restrict__ angle, int h, int w,
+    float segm_thresh, NmsCandidate* __restrict__ out, int capacity, int* __restrict__ count)
+{
+    __shared__ unsigned wave_total[16];
+    __shared__ unsigned base_s;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const int hw = h * w;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < hw; p0 += 1024) {
+        const int p = p0 + (int)tid;
+        const bool pass = p < hw && segm[p] > segm_thresh;
+        const unsigned long long m = __ballot(pass);
+        if (lane == 0) wave_total[wv] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned before = 0, total = 0;
+        for (unsigned k = 0; k < 16; ++k) {
+            const unsigned v = wave_total[k];
+            if (k < wv) before += v;
+            total += v;
+        }
+        const unsigned slot = base_s + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (pass && slot < (unsigned)capacity) {
+            const int y = p / w, x = p - y * w;
+            const float r0 = rbox[p], r1 = rbox[hw + p], r2 = rbox[2 * hw + p], r3 = rbox[3 * hw + p];
+            const float angle_sin = angle[p], angle_cos = angle[hw + p];   // a[0], a[1] (:84-85)
+            const float scale_factor = 4.0f, precision = 10000.0f;
+            const float xp = (float)x + 0.25f, yp = (float)y + 0.25f;
+            const float pos_r_x = (xp - r2 * angle_cos) * scale_factor;
+            const float pos_r_y = (yp - r2 * angle_sin) * scale_factor;
+            const float pos_r2_x = (xp + r3 * angle_cos) * scale_factor;
+            const float pos_r2_y = (yp + r3 * angle_sin) * scale_factor;
+            const float p_left = (float)exp((double)(-r2 / 9.0f)), p_top = (float)exp((double)(-r0 / 9.0f));
+            const float p_right = (float)exp((double)(-r3 / 9.0f)), p_bt = (float)exp((double)(-r1 / 9.0f));
+            NmsCandidate c;
+            c.quad[0] = (int)roundf(precision * (pos_r_x - r1 * angle_sin * scale_factor));
+            c.quad[1] = (int)roundf(precision * (pos_r_y + r1 * angle_cos * scale_factor));
+            c.quad[2] = (int)roundf(precision * (pos_r_x + r0 * angle_sin * scale_factor));
+            c.quad[3] = (int)roundf(precision * (pos_r_y - r0 * angle_cos * scale_factor));
+            c.quad[4] = (int)roundf(precision * (pos_r2_x + r0 * angle_sin * scale_factor));
+            c.quad[5] = (int)roundf(precision * (pos_r2_y - r0 * angle_cos * scale_factor));
+            c.quad[6] = (int)roundf(precision * (pos_r2_x - r1 * angle_sin * scale_factor));
+            c.quad[7] = (int)roundf(precision * (pos_r2_y + r1 * angle_cos * scale_factor));
+            c.score = segm[p];
+            c.probs[0] = p_left * p_bt;
+            c.probs[1] = p_left * p_top;
+            c.probs[2] = p_right * p_top;
+            c.probs[3] = p_right * p_bt;
+            c.x = x;
+            c.y = y;
+            c.pad = 0;
+            out[slot] = c;
+        }
+        __syncthreads();
+        if (tid == 0) base_s += total;
+        __syncthreads();
+    }
+    if (tid == 0) *count = (int)base_s;  // may exceed `capacity`: the caller sees how many there were
+}

@@ -89,6 +89,23 @@ def measure(device, reps=5, channels_last=False):
                          "backbone_ms_per_image": round(float(np.median(a[:, 0])) * 1e3, 3),
                          "recognition_ms_per_image": round(float(np.median(a[:, 1])) * 1e3, 3)}
             same = texts if same is None else (same == texts)
+    # the detector's post-processing on its own (see the module docstring): 24 words at 1280 x 704
+    from rroi_align.nms import get_boxes
+    from .pipeline import synthetic_detector_maps
+    maps = [tuple(torch.from_numpy(a).to(device) for a in synthetic_detector_maps(704, 1280, BOXES_PER_IMAGE, seed=i))
+            for i in range(len(ims))]
+    times, found = [], 0
+    for rep in range(reps + 1):
+        for m in maps:
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            b = get_boxes(*m, 0.5)
+            if rep:
+                times.append(time.perf_counter() - t0)
+                found += len(b)
+    out["nms"] = {"ms_per_image": round(float(np.median(times)) * 1e3, 3), "boxes_per_image": round(found / len(times), 1),
+                  "what": "rroi_align.nms.get_boxes on synthetic trained-detector maps (176 x 320, %d words): device "
+                          "decode + read-back of the passing pixels + host merge" % BOXES_PER_IMAGE}
     out["what"] = ("configs[4]: %s -> 1280x704, FOTSNet (ModelResNetSep2 restated, random weights), %d seeded boxes per "
                    "image, RoIRotate 11 x target_gw on the 64-ch 1/4 map, CRNN head, greedy CTC; median per-image time over %d passes over "
                    "the images; per_box = the reference's loop (R = 1 launch, head and decode per word), batched = one "

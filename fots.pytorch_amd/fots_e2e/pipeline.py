@@ -73,6 +73,32 @@ def synthetic_boxes(n, height, width, seed=0):
     return out
 
 
+def synthetic_detector_maps(height, width, nwords, seed=0):
+    """score (h, w), rbox (4, h, w), angle (2, h, w) fp32 numpy at 1/4 of a height x width image: what a
+    TRAINED detector emits for `nwords` rotated words (score inside the shrunk box, distances to the
+    four sides, unit direction) -- input for timing `rroi_align.nms.get_boxes`, which random
+    detection weights cannot exercise."""
+    h, w = height // 4, width // 4
+    rng = np.random.default_rng(seed)
+    segm, geo, ang = np.zeros((h, w), np.float32), np.zeros((4, h, w), np.float32), np.zeros((2, h, w), np.float32)
+    ang[1] = 1
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+    for _ in range(nwords):
+        cx, cy = rng.uniform(10, w - 10), rng.uniform(6, h - 6)
+        bh = rng.uniform(3, 8)
+        bw = bh * rng.uniform(2, 7)
+        a = rng.uniform(-0.5, 0.5)
+        c, s = np.cos(a), np.sin(a)
+        u = (xs + 0.25 - cx) * c + (ys + 0.25 - cy) * s
+        v = -(xs + 0.25 - cx) * s + (ys + 0.25 - cy) * c
+        inside = (np.abs(u) < bw / 2 * 0.8) & (np.abs(v) < bh / 2 * 0.6)
+        segm[inside] = rng.uniform(0.6, 0.99, inside.sum())
+        for k, d in enumerate((v + bh / 2, bh / 2 - v, u + bw / 2, bw / 2 - u)):
+            geo[k][inside] = np.maximum(d[inside], 0)
+        ang[0][inside], ang[1][inside] = s, c
+    return segm, geo, ang
+
+
 def host_roi(box):
     """One box -> ([0, int(cx), int(cy), h, w, angle], target_gw) as `align_ocr` computes them on
     the host (tools/ocr_utils.py:133-150): numpy fp32 corner arithmetic, Python-float sqrt/atan2."""

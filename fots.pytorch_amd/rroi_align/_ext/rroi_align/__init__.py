@@ -55,6 +55,10 @@ _lib.rroi_align_quads_to_rois_hip.restype = _i
 _lib.rroi_align_quads_to_rois_hip.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]
 _lib.rroi_align_gt_quads_to_rois_hip.restype = _i
 _lib.rroi_align_gt_quads_to_rois_hip.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp]
+_lib.rroi_rbox_decode_hip.restype = _i
+_lib.rroi_rbox_decode_hip.argtypes = [_vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _vp]
+_lib.rroi_nms_merge_host.restype = _i
+_lib.rroi_nms_merge_host.argtypes = [_vp, _i, _i, _i, _f, _f, _vp, _i]
 _lib.rroi_ctc_greedy_decode_hip.restype = _i
 _lib.rroi_ctc_greedy_decode_hip.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.rroi_align_sincos_probe_hip.restype = _i
@@ -70,7 +74,7 @@ EXPORTS = (
     "rroi_align_backward_workspace_bytes", "rroi_align_bin_centres_hip",
     "rroi_align_sincos_probe_hip", "rroi_align_quads_to_rois_hip", "rroi_align_hip_version",
     "rroi_ctc_greedy_decode_hip", "rroi_align_backward_layout_hip", "rroi_align_forward_layout_hip",
-    "rroi_align_gt_quads_to_rois_hip",
+    "rroi_align_gt_quads_to_rois_hip", "rroi_rbox_decode_hip", "rroi_nms_merge_host",
 )
 
 

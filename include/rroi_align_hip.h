@@ -155,6 +155,26 @@ int rroi_align_quads_to_rois_hip(const float* quads, const float* batch_index, i
 int rroi_align_gt_quads_to_rois_hip(const float* quads, const float* batch_index, const float* height_jitter,
                                     int n, float* rois, float* max_ratio, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * 4. Detection post-processing, replacing
+ *    nms/adaptor.cpp:40-120 + nms/nms.h:116-215 (`nms.get_boxes`, nms/__init__.py:20-29).
+ *
+ *    rroi_rbox_decode_hip    device: every pixel of the score map `segm` (h, w) above
+ *        `segm_thresh` -> one 64-byte candidate record, in raster order: int32 quad[8] in
+ *        1/10000 px, float score, float probs[4], int32 x, y, pad (adaptor.cpp:76-117).
+ *        rbox (4, h, w) and angle (2, h, w) are CHANNELS-FIRST, as the network emits them
+ *        (the reference transposes on the host first).  *count receives the number of passing
+ *        pixels even when it exceeds `capacity` (records beyond it are dropped).
+ *    rroi_nms_merge_host     host (no GPU work): locality-aware merge with `iou_threshold`, then
+ *        polygon NMS with `iou_threshold2` (the reference passes 0.4 and 0.2) over `num_candidates`
+ *        records in host memory -> boxes (n, 9) fp32 [x0,y0,..,x3,y3 in px, score]; returns the
+ *        number of boxes found (writes at most max_boxes), or -1 on an invalid argument.
+ * ------------------------------------------------------------------------- */
+int rroi_rbox_decode_hip(const float* segm, const float* rbox, const float* angle, int height, int width,
+                         float segm_thresh, void* candidates, int capacity, int* count, void* stream);
+int rroi_nms_merge_host(const void* candidates, int num_candidates, int width, int height, float iou_threshold,
+                        float iou_threshold2, float* boxes, int max_boxes);
+
 /* Greedy CTC decode of the recognition logits computed from the crops: replaces the per-box
  * `labels_pred.max(1)` + Python loop of tools/ocr_utils.py:183-186 / src/utils.py:87-97
  * (strLabelConverter.decode, raw=False) for all boxes of an image in one launch.

@@ -1,0 +1,92 @@
+"""detection post-processing.
+
+CPU: the restatement (oracle/nms_oracle.py) and the product's host merge (`rroi_nms_merge_host`,
+a host-only entry point of the library) against `tests/golden/nms_cases.npz` -- boxes computed by
+the reference's OWN nms/ sources (make_nms_golden.py) on seeded detector maps, the 11 example-image
+sized ones included.  GPU: the device decode bit for bit on the quads, and `get_boxes` end to end."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from nms_cases import CASES, synth_maps
+from oracle import nms_oracle as NO
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nms_cases.npz")
+
+
+def _inputs(case, z):
+    name, (h, w), words, seed, noise = case
+    segm, geo, ang = synth_maps(h, w, words, seed, noise)
+    assert zlib.crc32(segm.tobytes() + geo.tobytes() + ang.tobytes()) == int(z[name + "_crc"]), "generator drifted"
+    return name, segm, geo, ang
+
+
+def _records(polys):
+    from rroi_align.nms import CANDIDATE
+    rec = np.zeros(len(polys), CANDIDATE)
+    for i, p in enumerate(polys):
+        rec[i]["quad"] = np.asarray(p["poly"], np.int64).reshape(8)
+        rec[i]["score"], rec[i]["probs"], rec[i]["x"], rec[i]["y"] = p["score"], p["probs"], p["x"], p["y"]
+    return rec
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_oracle_and_host_merge_equal_the_references_own_nms(case):
+    """Both reproduce every box the reference's build returns -- coordinates and scores bit for bit
+    (the polygon intersection differs from Clipper's only below fp32 resolution of the areas)."""
+    from rroi_align.nms import merge
+    z = np.load(GOLD)
+    name, segm, geo, ang = _inputs(case, z)
+    want = z[name + "_boxes"]
+    if segm.size <= 96 * 64:                       # the pure-Python restatement: small maps only
+        assert np.array_equal(NO.get_boxes(segm, geo, ang, 0.5), want)
+    polys = NO.decode(segm, geo, ang.swapaxes(0, 1).swapaxes(1, 2), 0.5)
+    assert len(polys) == int(z[name + "_pixels"])
+    got = merge(_records(polys), segm.shape[1], segm.shape[0])
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_merge_statement_quirks():
+    """nms.h:198/:201 append an unmerged polygon twice; standard_nms then folds the twins."""
+    from rroi_align.nms import merge
+    seg, geo, ang = synth_maps(32, 48, 1, 3)
+    polys = NO.decode(seg, geo, ang.swapaxes(0, 1).swapaxes(1, 2), 0.5)
+    far = dict(polys[0], poly=[[v[0] + 3000000, v[1] + 3000000] for v in polys[0]["poly"]], x=40, y=30)
+    boxes = merge(_records([polys[0], far]), 48, 32)
+    ref = NO.merge_iou([polys[0], far], 48, 32, 0.4, 0.2)
+    assert len(boxes) == len(ref) == 2
+    # the second polygon was appended twice and merged with its twin: score doubled
+    assert sorted(boxes[:, 8]) == sorted(float(p["score"]) for p in ref)
+    assert np.isclose(boxes[:, 8].max(), 2 * float(far["score"]))
+    with pytest.raises(ValueError):
+        merge(_records([dict(polys[0], x=99)]), 48, 32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES[::2], ids=[c[0] for c in CASES[::2]])
+def test_device_decode_and_get_boxes(case):
+    import torch
+    from rroi_align import nms as N
+    z = np.load(GOLD)
+    name, segm, geo, ang = _inputs(case, z)
+    dev = torch.device("cuda", 0)
+    S, G, A = torch.from_numpy(segm).to(dev), torch.from_numpy(geo.transpose(2, 0, 1).copy()).to(dev), torch.from_numpy(ang).to(dev)
+    rec, cnt = N.decode(S, G, A, 0.5)
+    n = int(cnt.item())
+    got = rec[:n].cpu().numpy().view(N.CANDIDATE).reshape(-1)
+    want = _records(NO.decode(segm, geo, ang.swapaxes(0, 1).swapaxes(1, 2), 0.5))
+    assert n == len(want) == int(z[name + "_pixels"])
+    for f in ("quad", "score", "x", "y"):          # raster order, quads and scores bit for bit
+        assert np.array_equal(got[f], want[f]), f
+    # corner confidences: exp in double rounded once on the device, the C library's expf on the host
+    ulp = np.abs(got["probs"].view(np.int32).astype(np.int64) - want["probs"].view(np.int32))
+    assert ulp.max() <= 2
+    boxes = N.get_boxes(S, G, A, 0.5)
+    ref = z[name + "_boxes"]
+    assert boxes.shape == ref.shape
+    assert np.abs(boxes[:, :8] - ref[:, :8]).max() <= 2e-3      # px; a last-place confidence moves a corner by 1e-4 px
+    assert np.allclose(boxes[:, 8], ref[:, 8], rtol=1e-6)
+    # the reference's call-site layout (numpy, rbox as (h, w, 4)) gives the same boxes
+    assert np.array_equal(N.get_boxes(segm, geo, ang, 0.5), boxes)
