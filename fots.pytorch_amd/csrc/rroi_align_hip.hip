@@ -55,33 +55,21 @@ inline int launch_status() { return status_of(hipGetLastError()); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
-// Per-device facts, cached by device ordinal (a process may drive several GPUs, one per thread).
-struct DeviceShape {
-    std::atomic<int> cus{0};     // 0 = not asked yet
-    std::atomic<int> fused{0};   // 0 = no census yet, 1 = block b runs on XCD b % 8, -1 = it does not
-};
+// CU count per device ordinal (a process may drive several GPUs, one per thread or per call):
+// grids are sized for the device that is current at the call.
 constexpr int kMaxDevices = 64;
-DeviceShape g_dev[kMaxDevices];
-
-int current_device()
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
-    return dev;
-}
+std::atomic<int> g_cus[kMaxDevices];
 
 int num_cus()
 {
-    DeviceShape& d = g_dev[current_device()];
-    int cus = d.cus.load(std::memory_order_relaxed);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    int cus = g_cus[dev].load(std::memory_order_relaxed);
     if (cus > 0) return cus;
     cus = 256;
-    int dev = 0;
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess &&
-        p.multiProcessorCount > 0)
-        cus = p.multiProcessorCount;
-    d.cus.store(cus, std::memory_order_relaxed);
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
+    g_cus[dev].store(cus, std::memory_order_relaxed);
     return cus;
 }
 
@@ -155,35 +143,26 @@ FastDiv make_fastdiv(unsigned d)
 }
 
 struct Workspace {
-    FusedCtl* ctl;
     Affine* aff;
-    size_t aff_stride;  // entries per table
     float* cm;
     size_t cm_bytes;
     size_t bytes;
 };
 
-constexpr size_t kCtlBytes = 40960;  // FusedCtl, padded
-static_assert(sizeof(FusedCtl) <= kCtlBytes, "control block fits its header");
-
-// [control block (zero between calls) | kXcds + 1 affine tables | chunk-major copy (B, nchunks, HW+1, 32)];
-// the copy is absent when channels-last features with C % 4 == 0 are consumed in place.  The
-// two-launch paths use affine table 0 only.
+// [affine table | chunk-major copy (B, nchunks, HW+1, 32)]; the copy is absent when
+// channels-last features with C % 4 == 0 are consumed in place.
 Workspace carve(void* ws, int batch_size, int channels, int height, int width, int num_rois,
                 int layout)
 {
     Workspace w;
-    w.aff_stride = align_up((size_t)(num_rois > 0 ? num_rois : 1) * sizeof(Affine), 256) / sizeof(Affine);
-    const size_t aff_bytes = (kXcds + 1) * w.aff_stride * sizeof(Affine);
+    const size_t aff_bytes = align_up((size_t)(num_rois > 0 ? num_rois : 1) * sizeof(Affine), 256);
     const size_t nchunks = (channels + kChunk - 1) / kChunk;
     w.cm_bytes = layout == RROI_LAYOUT_NHWC
                      ? 0
                      : align_up((size_t)batch_size * nchunks * ((size_t)height * row_pitch(width) + 1) * kLineBytes, 256);
-    char* b = reinterpret_cast<char*>(ws);
-    w.ctl = reinterpret_cast<FusedCtl*>(b);
-    w.aff = reinterpret_cast<Affine*>(b + kCtlBytes);
-    w.cm = reinterpret_cast<float*>(b + kCtlBytes + aff_bytes);
-    w.bytes = kCtlBytes + aff_bytes + w.cm_bytes;
+    w.aff = reinterpret_cast<Affine*>(ws);
+    w.cm = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + aff_bytes);
+    w.bytes = aff_bytes + w.cm_bytes;
     return w;
 }
 
@@ -266,7 +245,6 @@ bool pick_tiled_bwd(int batch_size, int channels, int height, int width, int num
     return out_elems >= 0.5e6 && out_elems >= map_elems / 16;
 }
 
-int g_allow_fused = 1;  // exploration: 0 = AUTO never takes the one-launch path
 int g_store_aux = 2;   // cache policy of the output stores (see buf_store); 16 / 0 for exploration
 int g_fwd_dbg = 0;     // ablation: 1 = skip output stores, 2 = all taps out of range
 int g_prologue_blocks_per_cu = 3;
@@ -280,7 +258,7 @@ int g_bwd_relayout_aux = 2;
 // ====================================================================================
 extern "C" {
 
-const char* rroi_align_hip_version(void) { return "rroi_align_hip 0.4.0 gfx950"; }
+const char* rroi_align_hip_version(void) { return "rroi_align_hip 0.3.0 gfx950"; }
 
 size_t rroi_align_forward_workspace_bytes(int batch_size, int channels, int height, int width,
                                           int num_rois, int feature_layout)
@@ -297,44 +275,6 @@ size_t rroi_align_backward_workspace_bytes(int batch_size, int channels, int hei
         return 0;
     return carve_bwd(nullptr, batch_size, channels, height, width, num_rois,
                      pooled_height * pooled_width).bytes;
-}
-
-int rroi_align_workspace_init_hip(void* workspace, size_t workspace_bytes, void* stream_)
-{
-    if (!workspace || workspace_bytes < kCtlBytes) return 0;
-    return status_of(hipMemsetAsync(workspace, 0, kCtlBytes, static_cast<hipStream_t>(stream_)));
-}
-
-int rroi_align_workspace_status_hip(const void* workspace, void* stream_)
-{
-    if (!workspace) return 0;
-    unsigned err = 0;
-    hipError_t e = hipMemcpyAsync(&err, &static_cast<const FusedCtl*>(workspace)->error, sizeof err,
-                                  hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream_));
-    if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream_));
-    if (e != hipSuccess) return status_of(e);
-    return err == 0 ? 1 : -(int)(1000 + err);
-}
-
-int rroi_align_device_init_hip(void)
-{
-    DeviceShape& d = g_dev[current_device()];
-    int st = d.fused.load(std::memory_order_acquire);
-    if (st != 0) return st == 1 ? 1 : 0;
-    // census: a grid shaped like the one-launch forward's, twice; block b must report XCC b % 8
-    const int grid = num_cus() * g_waves_per_cu / (int)kXcds * (int)kXcds;
-    unsigned* rec = nullptr;
-    if (hipMalloc(&rec, (size_t)grid * sizeof(unsigned)) != hipSuccess) return 0;
-    bool ok = true;
-    std::vector<unsigned> host((size_t)grid);
-    for (int rep = 0; rep < 2 && ok; ++rep) {
-        hipLaunchKernelGGL(rroi_xcc_census_kernel, dim3(grid), dim3(kWave), 0, nullptr, rec);
-        ok = hipMemcpy(host.data(), rec, (size_t)grid * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess;
-        for (int b = 0; b < grid && ok; ++b) ok = host[(size_t)b] == (unsigned)(b % (int)kXcds);
-    }
-    (void)hipFree(rec);
-    d.fused.store(ok ? 1 : -1, std::memory_order_release);
-    return ok ? 1 : 0;
 }
 
 int rroi_align_forward_hip(const float* features, int feature_layout, float spatial_scale,
@@ -392,10 +332,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     if (!shape_ok(batch_size, num_rois, height, width, channels, pooled_height, pooled_width))
         return 0;
     if (feature_layout != RROI_LAYOUT_NCHW && feature_layout != RROI_LAYOUT_NHWC) return 0;
-    if (path != RROI_PATH_AUTO && path != RROI_PATH_DIRECT && path != RROI_PATH_TILED && path != RROI_PATH_FUSED)
-        return 0;
-    // the fused path is one launch: it reads NCHW features and cannot be run stage by stage
-    if (path == RROI_PATH_FUSED && (feature_layout != RROI_LAYOUT_NCHW || stages != RROI_STAGE_ALL)) return 0;
+    if (path != RROI_PATH_AUTO && path != RROI_PATH_DIRECT && path != RROI_PATH_TILED) return 0;
     if (num_rois == 0) return 1;
     if (!features || !rois || !top_data) return 0;
     const int NB = pooled_height * pooled_width;
@@ -407,7 +344,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         tiled = feature_layout == RROI_LAYOUT_NHWC ||
                 pick_tiled_fwd(batch_size, channels, height, width, num_rois, NB);
     else
-        tiled = path == RROI_PATH_TILED || path == RROI_PATH_FUSED;
+        tiled = path == RROI_PATH_TILED;
     if (!tiled && feature_layout != RROI_LAYOUT_NCHW) return 0;  // direct path reads NCHW only
 
     if (!tiled) {
@@ -429,72 +366,6 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     const bool zero_copy = feature_layout == RROI_LAYOUT_NHWC;
     const float* map = zero_copy ? features : ws.cm;
     const int pitch = row_pitch(width);
-
-    // One launch for the whole call when every XCD gets whole chunks (C a multiple of 256): the
-    // relayout is handed to the gather through each XCD's own L2 (see fwd_tiled_body).
-    const bool fused = !zero_copy && stages == RROI_STAGE_ALL && g_allow_fused &&
-                       (path == RROI_PATH_FUSED ||
-                        (path == RROI_PATH_AUTO && nchunks % (int)kXcds == 0 &&
-                         g_dev[current_device()].fused.load(std::memory_order_relaxed) == 1));
-    if (fused) {
-        const int ntiles = ceil_div(NB, kTileBins);
-        const int ptiles = ceil_div(HW, kTileBins);
-        const long items_per_chunk = (long)num_rois * ntiles;
-        if (items_per_chunk * nchunks >= (1L << 31) || (long)ptiles * batch_size * nchunks >= (1L << 30)) return 0;
-        // the resident set, in whole rounds of the 8 XCDs (every block of a group takes part in the
-        // hand-off, so a block must not wait for one that cannot become resident)
-        long grid = (long)num_cus() * g_waves_per_cu / kXcds * kXcds;
-        const long useful = (items_per_chunk + (long)ptiles * batch_size) * ((nchunks + kXcds - 1) / kXcds) * kXcds;
-        if (grid > useful) grid = useful;
-        if (grid < (long)kXcds) grid = kXcds;
-        SliceLayout lay;
-        lay.px_bytes = kLineBytes;
-        lay.row_bytes = (unsigned)pitch * kLineBytes;
-        lay.slice_bytes = (unsigned)height * lay.row_bytes;
-        lay.chunk_stride = ((unsigned)height * (unsigned)pitch + 1u) * kChunk;
-        lay.img_stride = lay.chunk_stride * (unsigned)nchunks;
-        FusedKernelArgs ka;
-        ka.out = top_data;
-        ka.num_rois = num_rois;
-        ka.C = channels;
-        ka.height = height;
-        ka.width = width;
-        ka.pooled_width = pooled_width;
-        ka.NB = NB;
-        ka.batch_size = batch_size;
-        ka.nchunks = nchunks;
-        ka.ntiles = ntiles;
-        ka.dbg = g_fwd_dbg;
-        ka.lay = lay;
-        ka.div_tiles = make_fastdiv((unsigned)ntiles);
-        ka.div_pw = make_fastdiv((unsigned)pooled_width);
-        FusedArgs& fa = ka.fa;
-        fa.nchw = features;
-        fa.rois = rois;
-        fa.ctl = ws.ctl;
-        fa.aff_tables = ws.aff;
-        fa.cm = ws.cm;
-        fa.aff_stride = (unsigned)ws.aff_stride;
-        fa.HW = HW;
-        fa.pitch = pitch;
-        fa.ptiles = ptiles;
-        fa.pooled_height = pooled_height;
-        fa.spatial_scale = spatial_scale;
-        fa.div_w = make_fastdiv((unsigned)width);
-        fa.div_ptiles = make_fastdiv((unsigned)ptiles);
-        fa.div_items_per_chunk = make_fastdiv((unsigned)items_per_chunk);
-        fa.div_units_per_chunk = make_fastdiv((unsigned)(ptiles * batch_size));
-#define RROI_LAUNCH_FUSED(VEC, AUX, ONHWC)                                                            \
-    hipLaunchKernelGGL((rroi_fwd_fused_kernel<VEC, AUX, ONHWC>), dim3((unsigned)grid), dim3(kWave), 0,  \
-                       stream, ka)
-        if (out_nhwc) RROI_LAUNCH_FUSED(true, 2, true);
-        else if (NB % 4 != 0) RROI_LAUNCH_FUSED(false, 2, false);
-        else if (g_store_aux == 16) RROI_LAUNCH_FUSED(true, 16, false);  // exploration only
-        else if (g_store_aux == 3) RROI_LAUNCH_FUSED(true, 3, false);    // exploration only
-        else RROI_LAUNCH_FUSED(true, 2, false);
-#undef RROI_LAUNCH_FUSED
-        return launch_status();
-    }
 
     // prologue: relayout + zero pixels + affine table in one launch
     if (stages & RROI_STAGE_PROLOGUE) {
@@ -563,12 +434,6 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
 // -DRROI_EXPLORE (tools/kbench.hip, `make EXPLORE=1`).  The product library does not export them;
 // the defaults above are the shipped configuration.
 #ifdef RROI_EXPLORE
-int rroi_align_debug_set_allow_fused(int v)
-{
-    const int old = g_allow_fused;
-    g_allow_fused = v;
-    return old;
-}
 int rroi_align_debug_set_store_aux(int v)
 {
     const int old = g_store_aux;

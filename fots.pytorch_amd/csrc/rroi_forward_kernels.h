@@ -177,199 +177,12 @@ __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois,
 // The three phases of consecutive items are interleaved around the store burst, see the
 // loop at the end.
 // ------------------------------------------------------------------------------------
-// ------------------------------------------------------------------------------------
-// Control block of the fused forward (workspace header; zero when the workspace is first used,
-// never reset afterwards: all counters are monotonic 64-bit).
-//
-// Work is dealt STATICALLY, exactly as in the two-launch kernel: block b serves chunk group
-// b % 8 as slot b / 8 of gridDim / 8.  What is new is the hand-off inside the launch: the
-// chunk-major copy of group x is produced by the blocks of group x and read by the same blocks,
-// through the L2 of the XCD they run on.  That is coherent iff all blocks of a group share one
-// XCD, which is how the hardware places them (block b -> XCD b % 8; measured, tools/kbench xcd)
-// but not something HIP promises -- so every block VERIFIES it (hardware XCC id == b % 8).  A
-// violation poisons `error` (sticky, read back by rroi_align_workspace_status_hip; the waiters
-// of that group then run into the poll bound), and AUTO takes the one-launch path only on a
-// device whose census (rroi_align_device_init_hip, once per device) shows the placement.
-//
-//   done[x][c]  blocks with b % 8 == x, (b / 8) % 16 == c whose share of the copy (and of the
-//               affine table) has reached the L2.  Every block adds 1 per call, so the value a
-//               block's own add returns, divided by the number of blocks in its class, is the
-//               CALL NUMBER n -- kernels on a stream are ordered, all adds of one call fall into
-//               one window -- and the gather of call n may start when every shard c has reached
-//               (n + 1) * (blocks in class c).  No reset, no last-block detection.
-// One 128-byte line per counter: same-line L2 atomics serialise at ~25-30 ns each (a first version
-// that claimed every item from one counter per XCD ran 270 us instead of 50).
-// ------------------------------------------------------------------------------------
-constexpr unsigned kXcds = 8;
-constexpr unsigned kShards = 16;
-constexpr unsigned kSpinCap = 1u << 20;   // bound on the poll loop (~1 s); expiry sets ctl->error
-
-struct FusedCounter {
-    unsigned long long v;
-    unsigned long long pad[15];
-};
-struct FusedCtl {
-    unsigned error;       // sticky bits: 1 = a poll loop expired, 2 = a block ran on an unexpected XCD
-    unsigned pad[31];
-    FusedCounter done[kXcds][kShards];
-};
-static_assert(sizeof(FusedCounter) == 128 && sizeof(FusedCtl) == 128 * (1 + kXcds * kShards), "one line per counter");
-
-__device__ __forceinline__ unsigned xcc_id()
-{
-    unsigned v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & 0xfu;
-}
-
-// L2-served load: sc1 bypasses the CU's L1 (MI355X_MICROARCH.md, "stores of each flavour")
-__device__ __forceinline__ unsigned long long l2_load(const unsigned long long* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Wave-uniform L2-scope 64-bit atomics, executed by lane 0 alone.  The exec mask is narrowed
-// INSIDE the asm statement, so the compiler sees straight-line code: no branch, no exec-masked
-// region of its own around a returning atomic (a `if (lane == 0) atomic` in this loop nest compiled
-// into a kernel that hung), and its s_waitcnt bookkeeping merely becomes conservative by the one
-// untracked operation.  No sc1: the atomic is performed in this XCD's L2.
-__device__ __forceinline__ void wave_add64(unsigned long long* p, unsigned long long v)
-{
-    unsigned long long save;
-    unsigned zero = 0;
-    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 "s_mov_b64 exec, 1\n\t"
-                 "global_atomic_add_x2 %[z], %[v], %[p]\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [sv] "=&s"(save)
-                 : [z] "v"(zero), [v] "v"(v), [p] "s"(p)
-                 : "memory");
-}
-// returning form: the old value lands in lane 0 of the result some time later -- pass it through
-// wave_wait64() before use
-__device__ __forceinline__ unsigned long long wave_fetch_add64(unsigned long long* p, unsigned long long v)
-{
-    unsigned long long save, old;
-    unsigned zero = 0;
-    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 "s_mov_b64 exec, 1\n\t"
-                 "global_atomic_add_x2 %[o], %[z], %[v], %[p] sc0\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [sv] "=&s"(save), [o] "=&v"(old)
-                 : [z] "v"(zero), [v] "v"(v), [p] "s"(p)
-                 : "memory");
-    return old;
-}
-__device__ __forceinline__ unsigned long long wave_wait64(unsigned long long v)
-{
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory");
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// blocks of the grid with b % 8 == x and (b / 8) % 16 == c;  units u < `units` with u % 16 == c
-__device__ __forceinline__ unsigned class_count(unsigned total, unsigned c)
-{
-    return total / kShards + (c < total % kShards ? 1u : 0u);
-}
-
-// FUSED = false: `map` is the finished chunk-major copy (or the caller's channels-last tensor), `aff`
-// the affine table, both written by an earlier launch; items are dealt statically
-// (k = blockIdx % nchunks).  FUSED = true: see rroi_fwd_fused_kernel below -- the block first helps
-// to produce `map` and `aff` for its XCD's chunk group and takes its items from a per-XCD counter.
-struct FusedArgs {
-    const float* nchw;        // (B, C, H, W) features
-    const float* rois;        // (R, 6)
-    FusedCtl* ctl;            // zero on entry, left zero on exit (workspace header)
-    Affine* aff_tables;       // kXcds + 1 private tables of `aff_stride` entries
-    float* cm;                // chunk-major copy being produced
-    unsigned aff_stride;
-    int HW, pitch, ptiles;    // pixels per image, row pitch of the copy, 64-pixel tiles per image
-    int pooled_height;
-    float spatial_scale;
-    FastDiv div_w, div_ptiles, div_items_per_chunk, div_units_per_chunk;
-};
-
-// One [32 ch] x [64 px] tile of image b, chunk k: NCHW -> chunk-major through the gather kernel's own
-// LDS tile T ([32][kTStride], XOR-swizzled): the inverse data path of its phases B and C.  Loads:
-// 16 lanes x 16 B = one 256-byte run of a channel row, 4 rows per instruction; stores: 8 lanes x 16 B
-// = the 128-byte line of a pixel, 8 pixels (1 KiB contiguous) per instruction.  Plain stores: the
-// lines stay in this XCD's L2, where the gather reads them.  Split in two so that the loads of a
-// wave's second tile (and its affine unit) are under way while the first goes through the LDS.
-struct RelayoutRegs {
-    v4f r[kChunk / 4];
-};
-
-__device__ __forceinline__ void fused_relayout_load(RelayoutRegs& R, const FusedArgs& fa, int C, unsigned b, unsigned k,
-                                                    unsigned pt, unsigned lane)
-{
-    const int HW = fa.HW;
-    const unsigned p0 = pt * (unsigned)kTileBins, c0 = k * kChunk;
-    const float* src = fa.nchw + ((size_t)b * C + c0) * HW + p0;
-    const bool vec_ok = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(fa.nchw) & 15) == 0;
-    const unsigned r4 = lane >> 4, p = (lane & 15u) * 4u;
-    // whole tile inside the map and 16-byte aligned rows: eight independent 16-byte loads, no
-    // per-lane branch (a divergent vector/scalar choice per row made the compiler drain vmcnt
-    // between the rows: eight serial round trips, 10 us instead of 2)
-    if (vec_ok && p0 + (unsigned)kTileBins <= (unsigned)HW && c0 + (unsigned)kChunk <= (unsigned)C) {
-#pragma unroll
-        for (int i = 0; i < kChunk / 4; ++i)
-            R.r[i] = *reinterpret_cast<const v4f*>(src + (size_t)((unsigned)i * 4u + r4) * HW + p);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < kChunk / 4; ++i) {
-        const unsigned c = (unsigned)i * 4u + r4;
-        v4f v = {0.f, 0.f, 0.f, 0.f};
-        if (c0 + c < (unsigned)C) {
-            const float* sp = src + (size_t)c * HW + p;
-            if (p0 + p + 0 < (unsigned)HW) v.x = sp[0];
-            if (p0 + p + 1 < (unsigned)HW) v.y = sp[1];
-            if (p0 + p + 2 < (unsigned)HW) v.z = sp[2];
-            if (p0 + p + 3 < (unsigned)HW) v.w = sp[3];
-        }
-        R.r[i] = v;
-    }
-}
-
-__device__ __forceinline__ void fused_relayout_store(float* T, const RelayoutRegs& R, const FusedArgs& fa, int width,
-                                                     int nchunks, unsigned b, unsigned k, unsigned pt, unsigned lane)
-{
-    const int HW = fa.HW;
-    const unsigned p0 = pt * (unsigned)kTileBins;
-    const unsigned r4 = lane >> 4, p = (lane & 15u) * 4u;
-#pragma unroll
-    for (int i = 0; i < kChunk / 4; ++i) {
-        const unsigned c = (unsigned)i * 4u + r4;
-        *reinterpret_cast<v4f*>(T + c * kTStride + (p ^ ((c >> 3) * 4u))) = R.r[i];
-    }
-    lds_wave_sync();
-    const size_t slice_stride = ((size_t)(HW / width) * fa.pitch + 1) * kChunk;
-    float* dst = fa.cm + ((size_t)b * nchunks + k) * slice_stride;
-    const unsigned cq = lane & 7u, pl = lane >> 3;
-#pragma unroll
-    for (int j = 0; j < kTileBins / 8; ++j) {
-        const unsigned px = (unsigned)j * 8u + pl;
-        const float* tr = T + (cq * 4u) * kTStride + (px ^ ((cq >> 1) * 4u));
-        const v4f v = {tr[0], tr[kTStride], tr[2 * kTStride], tr[3 * kTStride]};
-        const unsigned gp = p0 + px;
-        const unsigned y = fdiv(gp, fa.div_w);
-        const size_t pix = (size_t)y * fa.pitch + (gp - y * (unsigned)width);
-        if (gp < (unsigned)HW) *reinterpret_cast<v4f*>(dst + pix * kChunk + cq * 4u) = v;
-    }
-    lds_wave_sync();
-}
-
-// MODE 0: two-launch kernel (the copy and the affine table exist).  MODE 1: fused kernel.
-template <bool VEC_STORE, int AUX, bool ONHWC, int MODE>
-__device__ __forceinline__ unsigned fwd_tiled_body(
-    const float* __restrict__ map, const Affine* __restrict__ aff_in, float* __restrict__ out,
+template <bool VEC_STORE, int AUX, bool ONHWC = false>
+__global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
+    const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
-    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg,
-    const FusedArgs& fa)
+    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg)
 {
-    constexpr bool FUSED = MODE != 0;
     // A tile's bins are processed in CLASS-SORTED groups of 8, because the texture addresser
     // charges 16 cycles for every dwordx4 wave instruction whatever the number of lanes that
     // really fetch (measured: 16.1 / 15.6 / 15.2 clk with 0 / 50 / 87 % of the lanes out of
@@ -392,7 +205,10 @@ __device__ __forceinline__ unsigned fwd_tiled_body(
     __shared__ unsigned char HPbuf[2 * kRecs];
 
     const unsigned lane = threadIdx.x;
-    const unsigned items = (unsigned)num_rois * (unsigned)ntiles;  // per channel chunk
+    const unsigned k = blockIdx.x % (unsigned)nchunks;
+    const unsigned slot = blockIdx.x / (unsigned)nchunks;
+    const unsigned nslots = gridDim.x / (unsigned)nchunks;
+    const unsigned items = (unsigned)num_rois * (unsigned)ntiles;
     const unsigned px_bytes = lay.px_bytes;
     const unsigned row_bytes = lay.row_bytes;
 
@@ -401,17 +217,15 @@ __device__ __forceinline__ unsigned fwd_tiled_body(
     // accesses.  (With the quads strided over the wave every lane costs its own access:
     // measured 43 vs 16 TCP accesses per load instruction.)
     const unsigned q = lane & (kQuads - 1), b = lane >> 3;
-    // a channel quad wholly beyond C never loads (its rows are not stored either); depends on the
-    // item's chunk k, set by quad_offset() whenever the chunk changes
-    unsigned q_bytes = 0;
-    auto quad_offset = [&](unsigned k) { q_bytes = ((dbg & 2) || k * kChunk + q * 4 >= (unsigned)C) ? kQuadOOB : q * 16u; };
+    // a channel quad wholly beyond C never loads (its rows are not stored either)
+    const unsigned q_bytes = ((dbg & 2) || k * kChunk + q * 4 >= (unsigned)C) ? kQuadOOB : q * 16u;
     // LDS tile: row r = channel, 68-dword pitch; the column of rows 8m..8m+7 is XORed with
     // 4*m so that the 32 lanes of a store group (8 quads x 4 bins) spread over the banks
     // while rows stay 16-byte aligned for the ds_read_b128 of phase C.
     const unsigned wswz = (q >> 1) * 4u;  // rows 4q..4q+3 -> m = q >> 1
     const unsigned col = (lane & 15) * 4, row0 = lane >> 4;
+    const unsigned chans_here = min((unsigned)kChunk, (unsigned)C - k * kChunk);  // rows of this chunk < C
     const v4f z4 = {0.f, 0.f, 0.f, 0.f};
-    const Affine* __restrict__ aff = aff_in;  // FUSED: the table of the chunk group being served
 
     unsigned g_lo = 0, g_hi = 0;          // groups of the current item (wave-uniform)
     unsigned long long act_mask = 0;      // bins of the current item that are in a group
@@ -540,9 +354,8 @@ __device__ __forceinline__ unsigned fwd_tiled_body(
     // same on every path, or the compiler's s_waitcnt counts -- which take the most
     // conservative value where paths merge -- degrade to vmcnt(0) and every blend waits for
     // the store acknowledgements.  (Also the ablation knob: dbg & 1 drops the output stores.)
-    auto store_tile = [&](unsigned k, unsigned n, unsigned t, unsigned long long cur_mask, bool live) {
+    auto store_tile = [&](unsigned n, unsigned t, unsigned long long cur_mask, bool live) {
         live = live && !(dbg & 1);
-        const unsigned chans_here = min((unsigned)kChunk, (unsigned)C - k * kChunk);  // rows of this chunk < C
         if (ONHWC) {
             // channels-last output (R, PH*PW, C): lane = (channel quad q, bin b) as in phase B; a
             // store covers 8 bins x 128 B, the 32 channels of this chunk in each bin's 4*C-byte
@@ -612,238 +425,96 @@ __device__ __forceinline__ unsigned fwd_tiled_body(
     //   3. geometry of item i+1 -> record set p^1: ~250 instructions that depend on no memory
     //      access, run while the stores drain;
     //   4. phase B of item i -> T (its later groups do wait for the store acknowledgements).
-    //
-    // An item index e enumerates (j, n, t): the j-th chunk of the group being served (slowest, so
-    // that one slice is L2-hot at a time), roi n, 64-bin tile t; dealt statically: e = first,
-    // first + stride, ...  Two-launch kernel: the group is the single chunk k0 = blockIdx % nchunks.
-    // Fused kernel: the group is {k : k % 8 == blockIdx % 8}.
-    auto gather_pass = [&](auto&& chunk_of, unsigned total, unsigned first, unsigned stride) {
-        auto decode = [&](unsigned e, unsigned& k, unsigned& n, unsigned& t) {
-            unsigned rem = e;
-            unsigned j = 0;
-            if (FUSED) {
-                j = fdiv(e, fa.div_items_per_chunk);
-                rem = e - j * items;
+    unsigned cur = slot;
+    if (cur >= items) return;
+    unsigned n = fdiv(cur, div_tiles);
+    unsigned t = cur - n * (unsigned)ntiles;
+    unsigned p = 0;
+    unsigned n_prev = 0, t_prev = 0;
+    unsigned long long mask_prev = 0;
+    bool have_prev = false;
+    unsigned g_lo_next = 0, g_hi_next = 0;
+    unsigned long long mask_next = 0;
+    {
+        const Affine A = aff[n];
+        geometry(A, t, 0, g_lo, g_hi, act_mask);
+    }
+    int batch = aff[n].batch;
+    lds_wave_sync();
+
+    for (;;) {
+        const unsigned nxt = cur + nslots;
+        const bool has_next = nxt < items;
+        const unsigned n_next = has_next ? fdiv(nxt, div_tiles) : n;
+        const unsigned t_next = nxt - n_next * (unsigned)ntiles;
+        const Affine A_next = aff[n_next];  // scalar loads, in flight during steps 1-2
+
+        const bool batch_ok = batch >= 0 && batch < batch_size;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(
+            map + (size_t)(batch_ok ? batch : 0) * lay.img_stride + (size_t)k * lay.chunk_stride, lay.slice_bytes);
+        fetch_lo(p, 0, 0);
+        issue_lo(rs, 0);  // LO group 0 (there always is one)
+        store_tile(n_prev, t_prev, mask_prev, have_prev);
+        lds_wave_sync();  // T has been read: free for this item's blends
+        if (has_next) geometry(A_next, t_next, p ^ 1u, g_lo_next, g_hi_next, mask_next);
+
+        // ---- phase B: LO groups (group 0 is already in flight), then HI groups; the loads of
+        // group g+1 are issued before group g is blended.  The loops are unrolled with an early
+        // exit, and the two exit paths end in different (empty) asm statements so that the
+        // compiler cannot merge their tails: each blend then has ONE predecessor and its
+        // s_waitcnt knows exactly how many younger loads are in flight.
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int s = it & 1;
+            if ((unsigned)(it + 1) < g_lo) {
+                fetch_lo(p, it + 1, s ^ 1);
+                issue_lo(rs, s ^ 1);
+                pin_lo(s);
+                blend_lo(s);
+                asm volatile("; lo: more groups follow");
+            } else {
+                blend_lo(s);
+                asm volatile("; lo: last group");
+                break;
             }
-            k = chunk_of(j);
-            n = fdiv(rem, div_tiles);
-            t = rem - n * (unsigned)ntiles;
-        };
-        unsigned cur = first, nxt = first + stride;
-        if (cur >= total) return;
-        unsigned k, n, t;
-        decode(cur, k, n, t);
-        unsigned p = 0;
-        unsigned k_prev = k, n_prev = 0, t_prev = 0;
-        unsigned long long mask_prev = 0;
-        bool have_prev = false;
-        unsigned g_lo_next = 0, g_hi_next = 0;
-        unsigned long long mask_next = 0;
-        {
-            const Affine A = aff[n];
-            geometry(A, t, 0, g_lo, g_hi, act_mask);
         }
-        int batch = aff[n].batch;
-        quad_offset(k);
-        lds_wave_sync();
-
-        for (;;) {
-            const bool has_next = nxt < total;
-            unsigned k_next = k, n_next = n, t_next = 0;
-            if (has_next) decode(nxt, k_next, n_next, t_next);
-            const Affine A_next = aff[n_next];  // scalar loads, in flight during steps 1-2
-
-            const bool batch_ok = batch >= 0 && batch < batch_size;
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(
-                map + (size_t)(batch_ok ? batch : 0) * lay.img_stride + (size_t)k * lay.chunk_stride, lay.slice_bytes);
-            fetch_lo(p, 0, 0);
-            issue_lo(rs, 0);  // LO group 0 (there always is one)
-            store_tile(k_prev, n_prev, t_prev, mask_prev, have_prev);
-            lds_wave_sync();  // T has been read: free for this item's blends
-            if (has_next) geometry(A_next, t_next, p ^ 1u, g_lo_next, g_hi_next, mask_next);
-
-            // ---- phase B: LO groups (group 0 is already in flight), then HI groups; the loads of
-            // group g+1 are issued before group g is blended.  The loops are unrolled with an early
-            // exit, and the two exit paths end in different (empty) asm statements so that the
-            // compiler cannot merge their tails: each blend then has ONE predecessor and its
-            // s_waitcnt knows exactly how many younger loads are in flight.
+        if (g_hi > 0) {
+            fetch_hi(p, g_lo, 0);
+            issue_hi(rs, 0);
 #pragma unroll
             for (int it = 0; it < kIters; ++it) {
                 const int s = it & 1;
-                if ((unsigned)(it + 1) < g_lo) {
-                    fetch_lo(p, it + 1, s ^ 1);
-                    issue_lo(rs, s ^ 1);
-                    pin_lo(s);
-                    blend_lo(s);
-                    asm volatile("; lo: more groups follow");
+                if ((unsigned)(it + 1) < g_hi) {
+                    fetch_hi(p, g_lo + it + 1, s ^ 1);
+                    issue_hi(rs, s ^ 1);
+                    pin_hi(s);
+                    blend_hi(s);
+                    asm volatile("; hi: more groups follow");
                 } else {
-                    blend_lo(s);
-                    asm volatile("; lo: last group");
+                    blend_hi(s);
+                    asm volatile("; hi: last group");
                     break;
                 }
             }
-            if (g_hi > 0) {
-                fetch_hi(p, g_lo, 0);
-                issue_hi(rs, 0);
-#pragma unroll
-                for (int it = 0; it < kIters; ++it) {
-                    const int s = it & 1;
-                    if ((unsigned)(it + 1) < g_hi) {
-                        fetch_hi(p, g_lo + it + 1, s ^ 1);
-                        issue_hi(rs, s ^ 1);
-                        pin_hi(s);
-                        blend_hi(s);
-                        asm volatile("; hi: more groups follow");
-                    } else {
-                        blend_hi(s);
-                        asm volatile("; hi: last group");
-                        break;
-                    }
-                }
-            }
-            lds_wave_sync();  // T complete; record set p^1 complete
-            if (!has_next) {
-                store_tile(k, n, t, act_mask, true);
-                break;
-            }
-            k_prev = k;
-            n_prev = n;
-            t_prev = t;
-            mask_prev = act_mask;
-            have_prev = true;
-            cur = nxt;
-            nxt += stride;
-            k = k_next;
-            n = n_next;
-            t = t_next;
-            batch = A_next.batch;
-            quad_offset(k);
-            g_lo = g_lo_next;
-            g_hi = g_hi_next;
-            act_mask = mask_next;
-            p ^= 1u;
         }
-    };
-
-    if constexpr (!FUSED) {
-        const unsigned k0 = blockIdx.x % (unsigned)nchunks;
-        gather_pass([&](unsigned) { return k0; }, items, blockIdx.x / (unsigned)nchunks,
-                    gridDim.x / (unsigned)nchunks);
-    } else {
-        // ---- one launch: produce the chunk-major copy and the affine table, then gather ---------
-        // (see FusedCtl).  Hand-off: plain stores, s_waitcnt vmcnt(0), L2 atomic on one side;
-        // L2-served poll, then plain loads on the other -- no agent-scope write-back of the
-        // 3.3 MB slice, no invalidate: this CU's L1 cannot hold a line of the copy yet (it was
-        // invalidated when the kernel started and nothing has loaded from the copy since).
-        FusedCtl* const ctl = fa.ctl;
-        const unsigned g = blockIdx.x % kXcds, slot = blockIdx.x / kXcds;
-        const unsigned nslots = (gridDim.x - g + kXcds - 1u) / kXcds;  // blocks with b % 8 == g
-        const unsigned shard = slot % kShards;
-        const bool placed = xcc_id() == g;
-        if (!placed && lane == 0) __hip_atomic_fetch_or(&ctl->error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned cig = g < (unsigned)nchunks ? ((unsigned)nchunks - g + kXcds - 1u) / kXcds : 0u;
-        if (!cig) return 0u;
-        auto chunk_of = [&](unsigned j) -> unsigned { return g + kXcds * j; };
-        const unsigned aff_units = ((unsigned)num_rois + kWave - 1u) / kWave;
-        const unsigned tiles_per_chunk = (unsigned)batch_size * (unsigned)fa.ptiles;
-        const unsigned tiles = cig * tiles_per_chunk;
-        Affine* const aff_w = fa.aff_tables + (size_t)g * fa.aff_stride;
-        aff = aff_w;
-        auto tile_of = [&](unsigned v, unsigned& b, unsigned& k, unsigned& pt) {
-            const unsigned j = fdiv(v, fa.div_units_per_chunk);
-            const unsigned r = v - j * tiles_per_chunk;
-            b = fdiv(r, fa.div_ptiles);
-            k = chunk_of(j);
-            pt = r - b * (unsigned)fa.ptiles;
-        };
-        // produce: tiles slot, slot + nslots, ... two at a time (the loads of both in flight), the
-        // affine units on the LAST slots (those have the fewest tiles), under the first loads
-        if (!(dbg & 8)) {
-            bool first = true;
-            for (unsigned v0 = slot; v0 < tiles || first; v0 += 2u * nslots) {
-                RelayoutRegs ra, rb;
-                unsigned b0 = 0, k0 = 0, pt0 = 0, b1 = 0, k1 = 0, pt1 = 0;
-                const unsigned v1 = v0 + nslots;
-                const bool have0 = v0 < tiles, have1 = v1 < tiles;
-                if (have0) {
-                    tile_of(v0, b0, k0, pt0);
-                    if (!(dbg & 64)) fused_relayout_load(ra, fa, C, b0, k0, pt0, lane);
-                }
-                if (have1) {
-                    tile_of(v1, b1, k1, pt1);
-                    if (!(dbg & 64)) fused_relayout_load(rb, fa, C, b1, k1, pt1, lane);
-                }
-                if (first) {
-                    first = false;
-                    if (!(dbg & 16))
-                    for (unsigned u = nslots - 1u - slot; u < aff_units; u += nslots) {
-                        const unsigned n = u * kWave + lane;
-                        if (n < (unsigned)num_rois)
-                            aff_w[n] = make_affine(fa.rois + (size_t)n * 6, fa.pooled_height, fa.spatial_scale);
-                    }
-                }
-                if (have0 && !(dbg & 32)) fused_relayout_store(T, ra, fa, width, nchunks, b0, k0, pt0, lane);
-                if (have1 && !(dbg & 32)) fused_relayout_store(T, rb, fa, width, nchunks, b1, k1, pt1, lane);
-            }
+        lds_wave_sync();  // T complete; record set p^1 complete
+        if (!has_next) {
+            store_tile(n, t, act_mask, true);
+            break;
         }
-        // this block's share has reached the L2 before it is counted; the add also tells the call number
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long mine = wave_fetch_add64(&ctl->done[g][shard].v, 1ull);
-        {
-            const unsigned long long call = wave_wait64(mine) / class_count(nslots, shard);
-            const unsigned c = lane & (kShards - 1u);
-            const unsigned long long target = (call + 1ull) * class_count(nslots, c);
-            unsigned spins = 0;
-            for (;;) {
-                const bool ready = l2_load(&ctl->done[g][c].v) >= target;
-                if (__ballot(ready) == ~0ull) break;
-                if (++spins >= kSpinCap) {
-                    if (lane == 0) __hip_atomic_fetch_or(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (dbg & 4) return 0u;  // ablation: the produce phase and the hand-off alone
-        gather_pass(chunk_of, cig * items, slot, nslots);
+        n_prev = n;
+        t_prev = t;
+        mask_prev = act_mask;
+        have_prev = true;
+        cur = nxt;
+        n = n_next;
+        t = t_next;
+        batch = A_next.batch;
+        g_lo = g_lo_next;
+        g_hi = g_hi_next;
+        act_mask = mask_next;
+        p ^= 1u;
     }
-    return 0u;
-}
-
-template <bool VEC_STORE, int AUX, bool ONHWC = false>
-__global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
-    const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
-    int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
-    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg)
-{
-    FusedArgs none{};
-    fwd_tiled_body<VEC_STORE, AUX, ONHWC, 0>(map, aff, out, num_rois, C, height, width, pooled_width, NB,
-                                             batch_size, nchunks, ntiles, lay, div_tiles, div_pw, dbg, none);
-}
-
-// The whole forward call in ONE launch (NCHW features): relayout + affine tables + gather.
-struct FusedKernelArgs {
-    float* out;
-    int num_rois, C, height, width, pooled_width, NB, batch_size, nchunks, ntiles, dbg;
-    SliceLayout lay;
-    FastDiv div_tiles, div_pw;
-    FusedArgs fa;
-};
-
-template <bool VEC_STORE, int AUX, bool ONHWC = false>
-__global__ __launch_bounds__(kWave, 3) void rroi_fwd_fused_kernel(FusedKernelArgs a)  // 3 waves per SIMD = the 12 per CU the LDS admits
-{
-    fwd_tiled_body<VEC_STORE, AUX, ONHWC, 1>(a.fa.cm, a.fa.aff_tables, a.out, a.num_rois, a.C, a.height, a.width,
-                                             a.pooled_width, a.NB, a.batch_size, a.nchunks, a.ntiles, a.lay,
-                                             a.div_tiles, a.div_pw, a.dbg, a.fa);
-}
-
-// Census for fused_supported(): the raw XCC id of every block.
-__global__ __launch_bounds__(kWave) void rroi_xcc_census_kernel(unsigned* __restrict__ rec)
-{
-    if (threadIdx.x == 0) rec[blockIdx.x] = xcc_id();
 }
 
 // ------------------------------------------------------------------------------------

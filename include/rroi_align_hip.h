@@ -69,35 +69,13 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
 #define RROI_PATH_TILED 2  /* relayout to pixel-major + wave-tiled gather (large R) */
 #define RROI_PATH_TILED_ATOMIC 3 /* backward only: the tiled scatter with fp32 atomics (the
                                     default tiled backward is an atomic-free gather)         */
-#define RROI_PATH_FUSED 4  /* forward only, NCHW features: relayout + gather in ONE launch, the
-                              copy handed over through each XCD's own L2.  AUTO takes it when the
-                              channel count is a multiple of 256 (whole 32-channel chunks per XCD) */
 
 /* Bytes of scratch the tiled path needs for this problem (0 for the direct
  * path).  The caller owns the scratch; its contents are dead after the call. */
 size_t rroi_align_forward_workspace_bytes(int batch_size, int channels, int height, int width,
                                           int num_rois, int feature_layout);
-
-/* A forward workspace starts with a 40 KiB control block: the monotonic 64-bit counters through
- * which the one-launch path (RROI_PATH_FUSED) hands the relaid-out map from its producers to its
- * readers inside the launch.  It must be ZERO when the workspace is first used and is never reset
- * afterwards, so a workspace is initialised ONCE after it has been allocated (this call, or any
- * memset of its first 40 KiB) and then reused call after call.  The rest of the workspace needs
- * no initialisation.  Calls that may run concurrently (different streams) need different
- * workspaces. */
-int rroi_align_workspace_init_hip(void* workspace, size_t workspace_bytes, void* stream);
-
-/* Reads the control block's sticky error word back (synchronises `stream`): 1 = clean,
- * -(1000 + bits) otherwise (bit 0: a hand-off wait ran into its bound; bit 1: a block of the
- * one-launch kernel did not run on the XCD its index implies, see below). */
-int rroi_align_workspace_status_hip(const void* workspace, void* stream);
-
-/* One-time census of the current device (allocates, launches, synchronises -- call it outside
- * stream capture): the one-launch path hands data over through the L2 of the XCD that block b of a
- * grid runs on, and takes that to be XCD b % 8.  Every block verifies it at run time; this call
- * verifies it up front, and RROI_PATH_AUTO takes the one-launch path only on a device for which it
- * has returned 1.  Returns 1 (placement as expected) or 0. */
-int rroi_align_device_init_hip(void);
+size_t rroi_align_backward_workspace_bytes(int batch_size, int channels, int height, int width,
+                                           int num_rois, int pooled_height, int pooled_width);
 
 /* Forward.  top_data (R, C, PH, PW) is fully written.  rois whose batch index
  * falls outside [0, batch_size) produce zeros (the reference reads out of

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(64) void k_atomic(float* __restrict__ dst0, int ite
     }
 }
 
-// ---- XCD-local hand-off primitives (what rroi_fwd_fused_kernel relies on) ------------------
+// ---- XCD-local hand-off primitives (probed for the one-launch forward experiment of round 2,
+// tools/experiments/r02_fused_forward.patch; profiles/r02_fused_experiment.md) ---------------
 // rec[b] = raw XCC id register of block b; cnt[x*32] counts arrivals on XCD x with an L2-scope
 // atomic; every block then polls its XCD's counter (MODE 0: sc1 load, MODE 1: L2 atomic add 0,
 // MODE 2: plain load) until it reaches `expect` or `cap` polls; res[b] = polls used (cap = gave up).
@@ -314,68 +315,6 @@ int main(int argc, char** argv)
             fflush(stdout);
         }
         return 0;
-    }
-    if (argc > 1 && std::string(argv[1]) == "fused") {
-        // one-launch forward (RROI_PATH_FUSED) against the two-launch path: bit-for-bit, then timed
-        auto call = [&](int path) {
-            int rc = rroi_align_forward_hip(feat, 0, 0.25f, 1, R, H, W, C, PH, PW, rois_d, out, ws, wsb, path, 0);
-            if (rc != 1) { fprintf(stderr, "forward path=%d rc=%d\n", path, rc); exit(1); }
-        };
-        CK(hipMemset(ws, 0xff, wsb));                        // garbage everywhere ...
-        if (rroi_align_workspace_init_hip(ws, wsb, 0) != 1) return 1;  // ... except the header
-        std::vector<float> ref(out_elems), got(out_elems);
-        printf("device census (block b on XCD b %% 8): %d\n", rroi_align_device_init_hip());
-        {   // first call under a watchdog: a broken hand-off must not hold the box until gpurun's limit
-            hipEvent_t ev;
-            CK(hipEventCreate(&ev));
-            call(4);
-            CK(hipEventRecord(ev, 0));
-            for (int w = 0; w < 50 && hipEventQuery(ev) != hipSuccess; ++w) {
-                struct timespec ts = {0, 100000000};
-                nanosleep(&ts, nullptr);
-            }
-            if (hipEventQuery(ev) != hipSuccess) { printf("HUNG\n"); fflush(stdout); _exit(3); }
-            printf("first fused call done, workspace status %d\n", rroi_align_workspace_status_hip(ws, 0));
-            fflush(stdout);
-        }
-        CK(hipMemset(out, 0xff, out_elems * 4));
-        call(2);
-        CK(hipMemcpy(ref.data(), out, out_elems * 4, hipMemcpyDeviceToHost));
-        size_t bad_total = 0;
-        for (int rep = 0; rep < (argc > 2 ? 1 : 6); ++rep) {
-            CK(hipMemset(out, 0xff, out_elems * 4));
-            if (rep >= 3) for (int i = 0; i < 50; ++i) call(4);  // back-to-back reuse of the header
-            call(4);
-            CK(hipMemcpy(got.data(), out, out_elems * 4, hipMemcpyDeviceToHost));
-            size_t bad = 0;
-            for (size_t i = 0; i < out_elems; ++i) bad += memcmp(&ref[i], &got[i], 4) != 0;
-            const int wst = rroi_align_workspace_status_hip(ws, 0);
-            printf("fused rep %d: %zu of %zu elements differ from the two-launch path; workspace status %d\n",
-                   rep, bad, out_elems, wst);
-            fflush(stdout);
-            bad_total += bad + (wst != 1);
-        }
-        for (int i = 0; i < 300; ++i) call(4);  // clocks
-        CK(hipDeviceSynchronize());
-        for (int aux : {2, 16, 3}) {
-            rroi_align_debug_set_store_aux(aux);
-            char nm[96];
-            snprintf(nm, 96, "fused call, store aux=%d", aux);
-            report(nm, T.us([&] { call(4); }, 100), MB);
-            snprintf(nm, 96, "fused, 20 back-to-back, store aux=%d", aux);
-            report(nm, T.us([&] { for (int i = 0; i < 20; ++i) call(4); }, 20, 2) / 20, MB);
-            snprintf(nm, 96, "two-launch, 20 back-to-back, store aux=%d", aux);
-            report(nm, T.us([&] { for (int i = 0; i < 20; ++i) call(2); }, 20, 2) / 20, MB);
-        }
-        rroi_align_debug_set_store_aux(2);
-        for (int dbg : {4, 12, 4 + 16, 4 + 32, 4 + 64, 4 + 32 + 16, 4 + 64 + 32, 8, 9}) {
-            rroi_align_debug_set_fwd_dbg(dbg);
-            char nm[96];
-            snprintf(nm, 96, "fused, 20 back-to-back, ablation=%d", dbg);
-            report(nm, T.us([&] { for (int i = 0; i < 20; ++i) call(4); }, 20, 2) / 20, MB);
-        }
-        rroi_align_debug_set_fwd_dbg(0);
-        return bad_total ? 2 : 0;
     }
     if (argc > 1 && std::string(argv[1]) == "abl") {
         // gather-kernel ablations only: dbg bit 0 = no output stores, bit 1 = all taps out of range
