@@ -192,12 +192,16 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     //   HI  bins with four distinct taps (dx and dy):                4 loads per group;
     //   masked bins (pw > roi_pooled_width) are in no group -- phase C writes their zeros.
     // Typical tile: 5 LO + 2 HI groups = 18 load instructions instead of 32.
-    constexpr int kMaxGroups = kIters + 2;  // two classes, each padded to a multiple of 8
+    // two classes, each padded to a multiple of 8: ceil(a/8) + ceil(b/8) <= 9 for a + b <= 64 (and one
+    // forced LO group + 8 HI groups when a = 0)
+    constexpr int kMaxGroups = kIters + 1;
     constexpr unsigned kPadPos = kTileBins;  // "bin position" of a padding record
-    // T: rows 0..31 are the tile; the tail absorbs the writes of padding records (4 rows at the
-    // tile's pitch, 32 columns).  LDS is granted in 1280-byte granules on gfx950: the block must
-    // stay <= 12800 B for 12 waves per CU.
-    __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride + 3 * kTStride + 32];
+    // T: rows 0..31 are the tile, columns 0..63 of the 68-float pitch; the four spare columns of
+    // every row absorb the writes of padding records.  LDS is granted in 1280-byte granules on
+    // gfx950: the block (T 8704 + records 2448 = 11152 B) fits 9 granules, i.e. up to 14 waves per
+    // CU -- measured (tools/kbench abl, round 2): 12 waves 47.2 us, 13 48.0, 14 48.5: the kernel is
+    // bound by the write path, not by latency, and the grid stays at 12 per CU.
+    __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride];
     // tap records of two items: item i+1 is sampled out of one set while the other is being
     // built for item i+2
     constexpr int kRecs = kMaxGroups * kBinsPerIter;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         rbv[s] = buf_load(rs, ra[s].w + q_bytes);
     };
     float* const t_row = T + (q * 4) * kTStride;
-    float* const t_pad = T + kChunk * kTStride + (lane & 31u);
+    float* const t_pad = t_row + kTileBins + (b & 3u);  // columns 64..67 of this lane's four rows
     auto put = [&](unsigned pos, v4f v) {
         float* tw = pos < (unsigned)kTileBins ? t_row + (pos ^ wswz) : t_pad;
         tw[0 * kTStride] = v.x;

@@ -94,6 +94,31 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# Scratch for the tiled paths, one buffer per (device, stream), grown on demand and reused: calls on
+# one stream are ordered, so the next call may overwrite what the previous one left (the contents
+# are dead after a call); another stream gets its own buffer.  Saves the allocator round trip and,
+# for the backward at BASELINE configs[2], a 304 MB request per step.
+_scratch = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    if torch.cuda.is_current_stream_capturing():  # a graph owns its memory: nothing of it is cached
+        return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _scratch.pop(key, None)           # release the smaller buffer before asking for the larger one
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def release_workspaces() -> None:
+    """Drop the cached scratch buffers (they are re-created on demand)."""
+    _scratch.clear()
+
+
 def _require_cuda_f32(t: torch.Tensor, name: str) -> None:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
@@ -139,7 +164,7 @@ def forward(features: torch.Tensor, rois: torch.Tensor, pooled_height: int, pool
         if R == 0 or out.numel() == 0:
             return out
         nbytes = 0 if path == PATH_DIRECT else _lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, layout)
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=features.device)
+        ws = _workspace(features.device, nbytes)
         st = _lib.rroi_align_forward_layout_hip(features.data_ptr(), layout,
                                                 LAYOUT_NHWC if channels_last_out else LAYOUT_NCHW,
                                                 float(spatial_scale), B, R, H, W, C, ph, pw, rois.data_ptr(),
@@ -175,7 +200,7 @@ def backward(grad_output: torch.Tensor, rois: torch.Tensor, feature_size, spatia
         if grad_in.numel() == 0:
             return grad_in
         nbytes = 0 if path == PATH_DIRECT else _lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, ph, pw)
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=grad_output.device)
+        ws = _workspace(grad_output.device, nbytes)
         st = _lib.rroi_align_backward_layout_hip(grad_output.data_ptr(), layout,
                                                  LAYOUT_NHWC if cl_grad else LAYOUT_NCHW, float(spatial_scale),
                                                  B, R, H, W, C, ph, pw, rois.data_ptr(), grad_in.data_ptr(),

@@ -334,9 +334,9 @@ int main(int argc, char** argv)
             report(nm, pipe, MB);
         }
         rroi_align_debug_set_store_aux(2);
-        for (int wpc : {8, 12}) {
+        for (int wpc : {12, 13, 14}) {
             rroi_align_debug_set_waves_per_cu(wpc);
-            for (int dbg : {0, 1, 2, 3}) {
+            for (int dbg : {0, 1}) {
                 rroi_align_debug_set_fwd_dbg(dbg);
                 char nm[96];
                 snprintf(nm, 96, "gather %d waves/CU ablation=%d", wpc, dbg);
