@@ -82,8 +82,9 @@ def measure(device, reps=5, channels_last=False):
             wall = time.perf_counter() - t0
             a = np.asarray(samples)
             med = float(np.median(a.sum(1)))
-            # the median per-image time is the steady state; the mean also carries the host's
-            # occasional 40-80 ms stalls (allocator / first-use kernel selection), seen in both paths
+            # the median per-image time is the steady state; the mean also carries the 70-80 ms stalls
+            # that about every third image's host-side synchronisation wait runs into on the pool's
+            # boxes (tools/e2e_layouts.py: no device allocation or free coincides with them), in both paths
             out[name] = {"images_per_s": round(1.0 / med, 2),
                          "images_per_s_mean": round(len(samples) / wall, 2),
                          "backbone_ms_per_image": round(float(np.median(a[:, 0])) * 1e3, 3),
