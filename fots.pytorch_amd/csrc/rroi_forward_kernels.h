@@ -196,12 +196,14 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     // forced LO group + 8 HI groups when a = 0)
     constexpr int kMaxGroups = kIters + 1;
     constexpr unsigned kPadPos = kTileBins;  // "bin position" of a padding record
-    // T: rows 0..31 are the tile, columns 0..63 of the 68-float pitch; the four spare columns of
-    // every row absorb the writes of padding records.  LDS is granted in 1280-byte granules on
-    // gfx950: the block (T 8704 + records 2448 = 11152 B) fits 9 granules, i.e. up to 14 waves per
-    // CU -- measured (tools/kbench abl, round 2): 12 waves 47.2 us, 13 48.0, 14 48.5: the kernel is
-    // bound by the write path, not by latency, and the grid stays at 12 per CU.
-    __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride];
+    // T: rows 0..31 are the tile; the tail absorbs the writes of padding records (4 rows at the
+    // tile's pitch, 32 columns: 32 different banks).  LDS is granted in 1280-byte granules on gfx950;
+    // the block (T 9648 + records 2448 = 12096 B) stays within the 10 granules that 12 waves per CU
+    // allow.  Round 2 also tried a block of 11152 B (padding writes into the four spare columns of the
+    // tile pitch), which admits 14 waves per CU: 12 waves 47.2 us, 13 48.0, 14 48.5 (tools/kbench abl)
+    // -- the kernel is bound by the write path, not by latency -- and the spare-column writes are
+    // 4-way bank-conflicted (SQ_LDS_BANK_CONFLICT 40 % instead of 32 % of the LDS cycles): not kept.
+    __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride + 3 * kTStride + 32];
     // tap records of two items: item i+1 is sampled out of one set while the other is being
     // built for item i+2
     constexpr int kRecs = kMaxGroups * kBinsPerIter;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         rbv[s] = buf_load(rs, ra[s].w + q_bytes);
     };
     float* const t_row = T + (q * 4) * kTStride;
-    float* const t_pad = t_row + kTileBins + (b & 3u);  // columns 64..67 of this lane's four rows
+    float* const t_pad = T + kChunk * kTStride + (lane & 31u);
     auto put = [&](unsigned pos, v4f v) {
         float* tw = pos < (unsigned)kTileBins ? t_row + (pos ^ wswz) : t_pad;
         tw[0 * kTStride] = v.x;
