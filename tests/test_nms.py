@@ -48,6 +48,38 @@ def test_oracle_and_host_merge_equal_the_references_own_nms(case):
     assert got.shape == want.shape and np.array_equal(got, want)
 
 
+def _reference_adaptor():
+    """The reference's own nms extension, built by `make -C oracle ref` (oracle/_ref travels as a binary)."""
+    import importlib
+    import sys
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "nms_ref")
+    if not os.path.exists(os.path.join(d, "adaptor.so")):
+        if os.path.isdir("/root/reference"):
+            pytest.fail("oracle/_ref/nms_ref/adaptor.so is not built although /root/reference is here: `make -C oracle ref`")
+        pytest.skip("oracle/_ref/nms_ref not built")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    return importlib.import_module("adaptor")
+
+
+def test_host_merge_equals_reference_build_on_random_maps():
+    """Beyond the frozen cases: 60 more seeded detector maps (different sizes, word counts, noise
+    levels, thresholds), the product's host merge against the reference's own build run on the spot."""
+    from rroi_align.nms import merge
+    adaptor = _reference_adaptor()
+    rng = np.random.default_rng(123)
+    for trial in range(60):
+        h, w = int(rng.integers(24, 96)), int(rng.integers(40, 160))
+        segm, geo, ang = synth_maps(h, w, int(rng.integers(1, 9)), 1000 + trial, float(rng.uniform(0, 0.4)))
+        thr = float(rng.choice([0.5, 0.65, 0.8]))
+        a_hw2 = np.ascontiguousarray(ang.swapaxes(0, 1).swapaxes(1, 2))
+        want = np.array(adaptor.do_nms(segm, geo, a_hw2, np.full((h, w), -1, np.int32), 0.4, 0.2, thr), dtype="float32").reshape(-1, 9)
+        if len(want):
+            want[:, :8] /= 10000
+        got = merge(_records(NO.decode(segm, geo, a_hw2, thr)), w, h)
+        assert got.shape == want.shape and np.array_equal(got, want), (trial, h, w, thr)
+
+
 def test_merge_statement_quirks():
     """nms.h:198/:201 append an unmerged polygon twice; standard_nms then folds the twins."""
     from rroi_align.nms import merge
