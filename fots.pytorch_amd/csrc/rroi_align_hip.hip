@@ -537,16 +537,24 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
     const int nchunks = ceil_div(channels, kChunk);
     const int pitch = row_pitch(width);
     const int ptiles = ceil_div((long)HW, kRelayoutPx);
-    hipLaunchKernelGGL(rroi_affine_kernel, dim3(ceil_div(num_rois, 256)), dim3(256), 0, stream,
-                       rois, num_rois, pooled_height, spatial_scale, ws.aff);
+    const bool gather = path != RROI_PATH_TILED_ATOMIC && ws.gather_ok;
+    {
+        // affine table; the gather path's pixel counters are cleared by the same launch
+        const unsigned nzero = gather ? ws.keys.keys : 0u;
+        int ablocks = ceil_div(num_rois, 256);
+        const int zblocks = nzero ? (int)std::min<long>(ceil_div((long)nzero, 1024), 2L * num_cus()) : 0;
+        if (zblocks > ablocks) ablocks = zblocks;
+        hipLaunchKernelGGL(rroi_affine_kernel, dim3(ablocks), dim3(256), 0, stream, rois, num_rois, pooled_height,
+                           spatial_scale, ws.aff, ws.cnt, nzero);
+    }
     int st = launch_status();
     if (st != 1) return st;
 
-    if (path != RROI_PATH_TILED_ATOMIC && ws.gather_ok) {
+    if (gather) {
         // (1) pixel -> (bin, weight) lists: count, scan, fill
         const KeyLayout KL = ws.keys;
-        hipError_t e = hipMemsetAsync(ws.cnt, 0, (size_t)KL.keys * sizeof(int), stream);
-        if (e != hipSuccess) return status_of(e);
+        // few scan blocks: every consumer block prefix-sums their totals itself (no second scan launch)
+        const int raw_bsum = ws.scan_blocks <= kInlineScanBlocks ? 1 : 0;
         // list entries name a 32-channel line of top_diff: in the relaid-out copy
         // (R, nchunks, NB + 1, 32), or in a channels-last top_diff (R, NB, C) consumed in place
         const unsigned lines_per_chunk = (unsigned)NB + 1u;
@@ -576,7 +584,8 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
     hipLaunchKernelGGL((rroi_bwd_pairs_relayout_kernel<FILL, SAUX>), dim3((unsigned)(pblocks + (BLOCKS))), \
                        dim3(256), 0, stream, ws.aff, num_rois, height, width, pooled_width, NB,          \
                        batch_size, lines_per_roi, dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs,       \
-                       pblocks, top_diff, ws.tdT, channels, nchunks, tt, (int)(BLOCKS), (int)(T0), (int)(T1))
+                       pblocks, top_diff, ws.tdT, channels, nchunks, tt, (int)(BLOCKS), (int)(T0), (int)(T1),            \
+                       ws.scan_blocks, raw_bsum)
         {
             const long blocks = relayout_grid(half);
             if (g_bwd_relayout_aux == 16) RROI_LAUNCH_PR(false, 16, blocks, 0, half);
@@ -585,7 +594,7 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
         }
         hipLaunchKernelGGL(rroi_scan1_kernel, dim3(ws.scan_blocks), dim3(1024), 0, stream, ws.cnt, ws.off,
                            ws.bsum, KL.keys);
-        hipLaunchKernelGGL(rroi_scan2_kernel, dim3(1), dim3(1024), 0, stream, ws.bsum, ws.scan_blocks);
+        if (!raw_bsum) hipLaunchKernelGGL(rroi_scan2_kernel, dim3(1), dim3(1024), 0, stream, ws.bsum, ws.scan_blocks);
         {
             const long blocks = relayout_grid(tiles - half);
             if (g_bwd_relayout_aux == 16) RROI_LAUNCH_PR(true, 16, blocks, half, tiles);
@@ -606,13 +615,13 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
             hipLaunchKernelGGL(rroi_bwd_gather_kernel<true>, dim3((unsigned)gblocks), dim3(256), 0, stream,
                                td_nhwc ? top_diff : ws.tdT, ws.off, ws.bsum, ws.pairs, bottom_diff, channels,
                                height, width, pitch, nchunks, chunk_stride, line_stride, sub_shift, KL,
-                               make_fastdiv(KL.Ht * KL.Wt), make_fastdiv(KL.Wt));
+                               make_fastdiv(KL.Ht * KL.Wt), make_fastdiv(KL.Wt), ws.scan_blocks, raw_bsum);
             return launch_status();  // written in place: no relayout back
         }
         hipLaunchKernelGGL(rroi_bwd_gather_kernel<false>, dim3((unsigned)gblocks), dim3(256), 0, stream,
                            td_nhwc ? top_diff : ws.tdT, ws.off, ws.bsum, ws.pairs, ws.gcm, channels, height,
                            width, pitch, nchunks, chunk_stride, line_stride, sub_shift, KL,
-                           make_fastdiv(KL.Ht * KL.Wt), make_fastdiv(KL.Wt));
+                           make_fastdiv(KL.Ht * KL.Wt), make_fastdiv(KL.Wt), ws.scan_blocks, raw_bsum);
         st = launch_status();
         if (st != 1) return st;
     } else {

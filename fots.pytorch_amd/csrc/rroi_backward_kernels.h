@@ -65,10 +65,33 @@ __device__ __forceinline__ void bin_pairs(const Affine& A, unsigned ph, unsigned
 
 constexpr unsigned kScanBlock = 4096;  // keys per block of the first scan level
 
-// list offset of key i after the two-level scan
-__device__ __forceinline__ unsigned list_offset(const unsigned* __restrict__ off, const unsigned* __restrict__ bsum, unsigned i)
+// list offset of key i after the two-level scan: off[] is local to the key's scan block, `bs` the
+// exclusive prefix of the scan blocks' totals
+__device__ __forceinline__ unsigned list_offset(const unsigned* __restrict__ off, const unsigned* __restrict__ bs, unsigned i)
 {
-    return off[i] + bsum[i / kScanBlock];
+    return off[i] + bs[i / kScanBlock];
+}
+
+// Up to kInlineScanBlocks block totals (256 K keys: any map up to 512 x 512 pixels per image) are
+// prefix-summed by every consumer block itself, in LDS, instead of by a launch of their own
+// (rroi_scan2_kernel, which stays for larger maps): returns the array list_offset() reads.
+constexpr unsigned kInlineScanBlocks = 64;
+__device__ __forceinline__ const unsigned* block_prefix(const unsigned* __restrict__ bsum, unsigned nblocks, bool raw,
+                                                        unsigned* lds)
+{
+    if (!raw) return bsum;   // scanned in place by rroi_scan2_kernel
+    if (threadIdx.x < kWave) {
+        const unsigned v = threadIdx.x < nblocks ? bsum[threadIdx.x] : 0u;
+        unsigned incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d, 64);
+            if ((int)threadIdx.x >= d) incl += o;
+        }
+        lds[threadIdx.x] = incl - v;
+    }
+    __syncthreads();
+    return lds;
 }
 
 // FILL == false: cnt[key] += 1 per pair.  FILL == true: cnt counts back down, handing out the
@@ -109,10 +132,11 @@ __global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
     int* __restrict__ cnt, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
     uint2* __restrict__ pairs, int pair_blocks, const float* __restrict__ top_diff,
     float* __restrict__ tdT, int C, int nchunks, int ptiles, int relayout_blocks, int tile_begin,
-    int tile_end)
+    int tile_end, unsigned scan_blocks, int raw_bsum)
 {
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
     if ((int)blockIdx.x < pair_blocks) {
+        if (FILL) bsum = block_prefix(bsum, scan_blocks, raw_bsum != 0, reinterpret_cast<unsigned*>(T));
         const unsigned total = (unsigned)num_rois * (unsigned)NB;
         for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += (unsigned)pair_blocks * 256u)
             pairs_body<FILL>(idx, aff, num_rois, height, width, pooled_width, NB, batch_size, lines_per_roi,
@@ -194,8 +218,10 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     const float* __restrict__ tdT, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
     const uint2* __restrict__ pairs, float* __restrict__ gcm, int C, int height, int width, int pitch,
     int nchunks, unsigned chunk_stride, unsigned line_stride, unsigned sub_shift, KeyLayout L,
-    FastDiv div_bt, FastDiv div_wt)
+    FastDiv div_bt, FastDiv div_wt, unsigned scan_blocks, int raw_bsum)
 {
+    __shared__ unsigned bs_lds[kInlineScanBlocks];
+    bsum = block_prefix(bsum, scan_blocks, raw_bsum != 0, bs_lds);  // before any thread leaves
     // Workgroup -> keys: the G = 2^(sub_shift-3) workgroups that cover one 8 x 4 key tile get
     // block indices that are equal modulo 8, i.e. run on ONE XCD: neighbouring pixels share
     // source lines (the 2 x 2 footprint of a bin), and only an XCD's own L2 can serve them twice.

@@ -157,11 +157,15 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
                                relayout_blocks, relayout_tiles, nullptr, 0);
 }
 
+// per-ROI affine table; the backward also has it clear its pixel counters (`zero`, `nzero` ints)
+// instead of paying a memset launch of their own
 __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois, int pooled_height,
-                                   float spatial_scale, Affine* __restrict__ aff)
+                                   float spatial_scale, Affine* __restrict__ aff, int* __restrict__ zero = nullptr,
+                                   unsigned nzero = 0)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned j = gid; j < nzero; j += gridDim.x * blockDim.x) zero[j] = 0;
+    if (gid < (unsigned)num_rois) aff[gid] = make_affine(rois + (size_t)gid * 6, pooled_height, spatial_scale);
 }
 
 // ------------------------------------------------------------------------------------
