@@ -316,6 +316,35 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    if (argc > 1 && std::string(argv[1]) == "pro") {
+        // prologue shape sweep: resident blocks per CU x store policy, as the whole step sees it
+        auto stage = [&](int st) {
+            int rc = rroi_align_forward_stages_hip(feat, 0, 0.25f, 1, R, H, W, C, PH, PW, rois_d, out, ws, wsb, 2, st, 0);
+            if (rc != 1) { fprintf(stderr, "stage rc=%d\n", rc); exit(1); }
+        };
+        for (int i = 0; i < 300; ++i) stage(3);
+        CK(hipDeviceSynchronize());
+        rroi_align_debug_set_prologue_blocks(3);
+        for (int rep = 0; rep < 5; ++rep)
+            for (int paux : {0, 16}) {   // A/B/A/B: is the write-through prologue better over the whole step?
+                rroi_align_debug_set_prologue_aux(paux);
+                char nm[96];
+                snprintf(nm, 96, "A/B %d: whole step, prologue aux=%d, 50 x 20 steps", rep, paux);
+                report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 50, 5) / 20, MB);
+            }
+        for (int paux : {0, 16}) {
+            rroi_align_debug_set_prologue_aux(paux);
+            for (int bpc : {3}) {
+                rroi_align_debug_set_prologue_blocks(bpc);
+                char nm[96];
+                snprintf(nm, 96, "prologue aux=%d blocks/CU=%d: 20 back-to-back", paux, bpc);
+                report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(1); }, 20, 3) / 20, 52.4);
+                snprintf(nm, 96, "  whole step, prologue aux=%d blocks/CU=%d", paux, bpc);
+                report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 20, 3) / 20, MB);
+            }
+        }
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "abl") {
         // gather-kernel ablations only: dbg bit 0 = no output stores, bit 1 = all taps out of range
         auto stage = [&](int s) {
