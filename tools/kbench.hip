@@ -316,6 +316,41 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    if (argc > 1 && std::string(argv[1]) == "order") {
+        // does the ORDER in which the ROIs are processed matter?  (spatially sorted ROIs keep a smaller
+        // part of the map slice hot in the L2 at any time)
+        auto stage = [&](int st) {
+            int rc = rroi_align_forward_stages_hip(feat, 0, 0.25f, 1, R, H, W, C, PH, PW, rois_d, out, ws, wsb, 2, st, 0);
+            if (rc != 1) { fprintf(stderr, "stage rc=%d\n", rc); exit(1); }
+        };
+        for (int i = 0; i < 300; ++i) stage(3);
+        CK(hipDeviceSynchronize());
+        std::vector<int> idx(R);
+        for (int mode = 0; mode < 4; ++mode) {
+            for (int i = 0; i < R; ++i) idx[i] = i;
+            auto morton = [&](int i) {
+                unsigned x = (unsigned)(hr[i * 6 + 1] * 0.25f) >> 3, y = (unsigned)(hr[i * 6 + 2] * 0.25f) >> 3, m = 0;
+                for (int b = 0; b < 6; ++b) m |= ((x >> b) & 1u) << (2 * b) | ((y >> b) & 1u) << (2 * b + 1);
+                return m;
+            };
+            if (mode == 1) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return hr[a * 6 + 2] < hr[b * 6 + 2]; });
+            if (mode == 2) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return morton(a) < morton(b); });
+            if (mode == 3) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {   // bands of 32 map rows, x inside
+                const int ba = (int)(hr[a * 6 + 2] * 0.25f) / 32, bb = (int)(hr[b * 6 + 2] * 0.25f) / 32;
+                return ba != bb ? ba < bb : hr[a * 6 + 1] < hr[b * 6 + 1]; });
+            std::vector<float> pr(R * 6);
+            for (int i = 0; i < R; ++i) for (int k = 0; k < 6; ++k) pr[i * 6 + k] = hr[idx[i] * 6 + k];
+            CK(hipMemcpy(rois_d, pr.data(), pr.size() * 4, hipMemcpyHostToDevice));
+            const char* nm4[4] = {"as generated", "sorted by centre y", "sorted by Morton code of the centre (8 px cells)", "32-row bands, x inside"};
+            char nm[128];
+            stage(3);
+            snprintf(nm, 128, "gather, ROIs %s", nm4[mode]);
+            report(nm, T.us([&] { stage(2); }, 200, 20), MB);
+            snprintf(nm, 128, "  whole step, ROIs %s", nm4[mode]);
+            report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 50, 5) / 20, MB);
+        }
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "pro") {
         // prologue shape sweep: resident blocks per CU x store policy, as the whole step sees it
         auto stage = [&](int st) {
