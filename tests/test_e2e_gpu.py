@@ -64,6 +64,22 @@ def test_batched_recognition_equals_the_per_word_loop(setup, size, nbox):
     assert len(widths) >= 2  # more than one pooled-width bucket was exercised
 
 
+def test_batched_recognition_edge_cases(setup):
+    """no box at all; one box; boxes that all fall into one pooled-width bucket"""
+    from fots_e2e.pipeline import batched, per_box, synthetic_boxes
+    net, conv, dev = setup
+    torch.manual_seed(4)
+    with torch.no_grad():
+        _, _, _, feats = net(torch.rand(1, 3, 128, 256, device=dev) * 2 - 1)
+        assert batched(net, conv, feats, np.zeros((0, 9), np.float32)) == []
+        assert per_box(net, conv, feats, np.zeros((0, 9), np.float32)) == []
+        boxes = synthetic_boxes(6, 128, 256, seed=2)
+        assert batched(net, conv, feats, boxes[:1]) == per_box(net, conv, feats, boxes[:1])
+        same = np.repeat(boxes[:1], 5, 0)
+        t, c, _ = batched(net, conv, feats, same, return_crops=True)
+        assert len(set(t)) == 1 and all(torch.equal(c[0], ci) for ci in c)
+
+
 def test_bench_e2e_measure_runs(setup):
     from fots_e2e.bench_e2e import measure
     _, _, dev = setup

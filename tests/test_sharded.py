@@ -52,6 +52,12 @@ def _worker(rank, world, port, R, gather, q):
         m = ShardedRRoiAlign(8, 16, 0.25, gather=gather, op=op)
         out = m(torch.from_numpy(f), torch.from_numpy(r))
         lo, hi = shard_bounds(R, world, rank)
+        if gather:  # the inference form: one collective straight into a preallocated buffer
+            from rroi_align.sharded import gather_crops
+            buf = torch.full_like(out, 7.0)
+            with torch.no_grad():
+                res = gather_crops(op(torch.from_numpy(f), torch.from_numpy(r[lo:hi])), R, out=buf)
+            assert res is buf and torch.equal(buf, out)
         gout = torch.from_numpy(O.forward_c(f, r[lo:hi], 8, 16, 0.25)) * 2
         g = torch.from_numpy(O.backward_c(gout.numpy(), r[lo:hi], f.shape, 0.25))
         g = allreduce_feature_grad(g)
