@@ -249,9 +249,11 @@ int g_store_aux = 2;   // cache policy of the output stores (see buf_store); 16 
 int g_fwd_dbg = 0;     // ablation: 1 = skip output stores, 2 = all taps out of range
 int g_prologue_blocks_per_cu = 3;
 int g_prologue_aux = 0;
-// store policy of the backward's top_diff relayout: streaming (nt) 189.5 us per call, sc1 191.3,
-// plain 194.0 (tools/bwd_profile.py with RROI_BWD_SWEEP=1); non-temporal LOADS in the gather: +16 us
-int g_bwd_relayout_aux = 2;
+// store policy of the backward's top_diff relayout (tools/bwd_profile.py with RROI_BWD_SWEEP=1, four
+// runs): write-through (sc1) 163.4-165.9 us per call, streaming (nt) 166.8-168.8, plain 166.2-169.2 --
+// write-through leaves no dirty lines for the end of the launch to flush.  (Round 1, with two more
+// launches in the call, had nt ahead by 2 us.)  Non-temporal LOADS in the gather: +16 us.
+int g_bwd_relayout_aux = 16;
 
 }  // namespace
 
