@@ -66,7 +66,9 @@ def cpu_baseline(feats, rois):
     sys.path.insert(0, ROOT)
     from oracle import rroi_align_oracle as O
     c = CFG
-    cores = O.max_threads()
+    from fots_e2e.hostcpus import effective_cpus
+    # OpenMP's default is the machine's hardware threads; the cgroup quota is what this process gets
+    cores = max(1, min(O.max_threads(), effective_cpus()))
     # bounded sample: 128 of the 512 ROIs on 1 thread (~1 s) and the full workload 6x on all cores
     t0 = time.perf_counter()
     O.forward_c(feats, rois[:128], c["PH"], c["PW"], c["scale"], threads=1)
@@ -144,6 +146,9 @@ def run(args):
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # the ranks of a node share its CPU quota: keep every rank's intra-op pool inside its share
+    from fots_e2e.hostcpus import effective_cpus
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), effective_cpus() // world)))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from .alphabet import ALPHABET
+from .hostcpus import cap_torch_threads
 from .model import FOTSNet
 from .pipeline import batched, per_box, preprocess, resize_rule, synthetic_boxes
 from .weights import deterministic_init
@@ -44,6 +45,7 @@ def load_images(limit=None):
 
 def measure(device, reps=5, channels_last=False):
     from rroi_align.decode import CTCLabelConverter
+    host_threads = cap_torch_threads()  # hostcpus.py: an oversized intra-op pool gets the process throttled
     net = deterministic_init(FOTSNet(len(ALPHABET) + 1)).eval().to(device)
     if channels_last:
         net = net.to(memory_format=torch.channels_last)
@@ -82,9 +84,8 @@ def measure(device, reps=5, channels_last=False):
             wall = time.perf_counter() - t0
             a = np.asarray(samples)
             med = float(np.median(a.sum(1)))
-            # the median per-image time is the steady state; the mean also carries the 70-80 ms stalls
-            # that about every third image's host-side synchronisation wait runs into on the pool's
-            # boxes (tools/e2e_layouts.py: no device allocation or free coincides with them), in both paths
+            # median per-image time and whole-pass mean: they agree once the intra-op pool is capped to
+            # the cgroup's CPU quota (before: 70-80 ms throttling stalls on every third image or so)
             out[name] = {"images_per_s": round(1.0 / med, 2),
                          "images_per_s_mean": round(len(samples) / wall, 2),
                          "backbone_ms_per_image": round(float(np.median(a[:, 0])) * 1e3, 3),
@@ -113,4 +114,5 @@ def measure(device, reps=5, channels_last=False):
                    "RoIRotate launch per image, head per width bucket" % (source, BOXES_PER_IMAGE, reps))
     out["last_image_texts_equal"] = bool(same) if isinstance(same, bool) else None
     out["speedup"] = round(out["batched"]["images_per_s"] / out["per_box"]["images_per_s"], 2)
+    out["host_threads"] = host_threads
     return out

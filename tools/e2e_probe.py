@@ -10,6 +10,8 @@ from fots_e2e.pipeline import batched, per_box, preprocess, resize_rule, synthet
 from fots_e2e.weights import deterministic_init
 from rroi_align.decode import CTCLabelConverter
 
+from fots_e2e.hostcpus import cap_torch_threads
+cap_torch_threads()
 dev = torch.device("cuda", 0)
 net = deterministic_init(FOTSNet(87)).eval().to(dev)
 conv = CTCLabelConverter(ALPHABET)
