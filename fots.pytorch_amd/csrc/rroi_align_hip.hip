@@ -43,6 +43,7 @@ namespace {
 #include "rroi_device_common.h"
 #include "rroi_forward_kernels.h"
 #include "rroi_backward_kernels.h"
+#include "rroi_backward_tile_kernels.h"
 #include "rroi_callers_kernels.h"
 #include "rroi_nms_kernels.h"
 #include "rroi_nms_host.h"
@@ -509,7 +510,7 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
     if (!shape_ok(batch_size, num_rois, height, width, channels, pooled_height, pooled_width))
         return 0;
     if (path != RROI_PATH_AUTO && path != RROI_PATH_DIRECT && path != RROI_PATH_TILED &&
-        path != RROI_PATH_TILED_ATOMIC)
+        path != RROI_PATH_TILED_ATOMIC && path != RROI_PATH_TILED_LISTS && path != RROI_PATH_TILED_INKERNEL)
         return 0;
     if (!bottom_diff) return 0;
     const int NB = pooled_height * pooled_width;
@@ -540,9 +541,21 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
     const int pitch = row_pitch(width);
     const int ptiles = ceil_div((long)HW, kRelayoutPx);
     const bool gather = path != RROI_PATH_TILED_ATOMIC && ws.gather_ok;
+    // Two gathers.  K3t builds the pixel lists inside the gather kernel (rroi_backward_tile_kernels.h), K3g
+    // with count / scan / fill launches in HBM.  Measured (tools/crossover.py, MI355X, us per call,
+    // K3t / K3g): C = 64, 176x320 map, 11x96: R = 4 26 / 33, 32 31 / 37, 128 41 / 49, 512 88 / 98;  C = 64,
+    // 8 images of 160x160, 11x100: 45 / 51, 54 / 54, 68 / 72, 133 / 148;  C = 256, 160x160, 8x64: 39 / 39,
+    // 43 / 40, 77 / 62, 201 / 168 -- K3t's serial work per tile is hidden when a lane carries two
+    // channel chunks, not when it carries eight.  K3t addresses its source with 32-bit byte offsets.
+    const size_t src_bytes = td_nhwc ? (size_t)num_rois * NB * channels * 4
+                                     : (size_t)num_rois * nchunks * ((size_t)NB + 1) * kLineBytes;
+    const bool inkernel_ok = src_bytes < (1ull << 32);
+    if (path == RROI_PATH_TILED_INKERNEL && !(gather && inkernel_ok)) return 0;
+    const bool lists = path == RROI_PATH_TILED_LISTS || !inkernel_ok ||
+                       (path != RROI_PATH_TILED_INKERNEL && nchunks > 2);
     {
-        // affine table; the gather path's pixel counters are cleared by the same launch
-        const unsigned nzero = gather ? ws.keys.keys : 0u;
+        // affine table; the list passes' pixel counters (K3g) are cleared by the same launch
+        const unsigned nzero = gather && lists ? ws.keys.keys : 0u;
         int ablocks = ceil_div(num_rois, 256);
         const int zblocks = nzero ? (int)std::min<long>(ceil_div((long)nzero, 1024), 2L * num_cus()) : 0;
         if (zblocks > ablocks) ablocks = zblocks;
@@ -552,6 +565,62 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
     int st = launch_status();
     if (st != 1) return st;
 
+    if (gather && !lists) {
+        // K3t: relayout of top_diff (one launch, masked bins skipped), then the tile gather
+        const KeyLayout KL = ws.keys;
+        const unsigned lines_per_chunk = (unsigned)NB + 1u;
+        const unsigned lines_per_roi = td_nhwc ? (unsigned)NB : lines_per_chunk * (unsigned)nchunks;
+        const unsigned chunk_stride = td_nhwc ? (unsigned)kChunk : lines_per_chunk * (unsigned)kChunk;
+        const unsigned line_stride = td_nhwc ? (unsigned)channels : (unsigned)kChunk;
+        const FastDiv dnb = make_fastdiv((unsigned)NB), dpw = make_fastdiv((unsigned)pooled_width);
+        if (!td_nhwc) {
+            const int tt = ceil_div(NB, kRelayoutPx);
+            const long tiles = (long)tt * nchunks * num_rois;
+            if (tiles >= (1L << 31)) return 0;
+            long unit = nchunks;
+            while (unit % 8) unit += nchunks;
+            long blocks = tiles;
+            const long cap = (long)num_cus() * 8;
+            if (blocks > cap) blocks = cap >= unit ? cap / unit * unit : cap;
+#define RROI_LAUNCH_R(SAUX)                                                                              \
+    hipLaunchKernelGGL((rroi_bwd_pairs_relayout_kernel<false, SAUX>), dim3((unsigned)blocks), dim3(256), 0,   \
+                       stream, ws.aff, num_rois, height, width, pooled_width, NB, batch_size, lines_per_roi, \
+                       dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs, 0, top_diff, ws.tdT, channels,       \
+                       nchunks, tt, (int)blocks, 0, (int)tiles, ws.scan_blocks, 0)
+            if (g_bwd_relayout_aux == 16) RROI_LAUNCH_R(16);
+            else if (g_bwd_relayout_aux == 2) RROI_LAUNCH_R(2);
+            else RROI_LAUNCH_R(0);
+#undef RROI_LAUNCH_R
+            st = launch_status();
+            if (st != 1) return st;
+        }
+        const unsigned ntiles = KL.keys / 32u;
+        const unsigned per_xcd = (ntiles + 7u) / 8u;
+        const FastDiv dbt = make_fastdiv(KL.Ht * KL.Wt), dwt = make_fastdiv(KL.Wt), dph = make_fastdiv((unsigned)pooled_height);
+        float* dst = bd_nhwc ? bottom_diff : ws.gcm;
+        const float* srcT = td_nhwc ? top_diff : ws.tdT;
+#define RROI_LAUNCH_TG(NK, NHWC)                                                                          \
+    hipLaunchKernelGGL((rroi_bwd_tile_gather_kernel<NK, NHWC>), dim3(per_xcd * 8u), dim3(kTgThreads), 0, stream, \
+                       srcT, ws.aff, dst, num_rois, channels, height, width, pitch, pooled_height,           \
+                       pooled_width, batch_size, nchunks, chunk_stride, line_stride, lines_per_roi, KL,      \
+                       ntiles, per_xcd, dbt, dwt, dph)
+#define RROI_LAUNCH_TG_NK(NHWC)                          \
+    do {                                                 \
+        if (nchunks > 4) RROI_LAUNCH_TG(8, NHWC);        \
+        else if (nchunks > 2) RROI_LAUNCH_TG(4, NHWC);   \
+        else if (nchunks > 1) RROI_LAUNCH_TG(2, NHWC);   \
+        else RROI_LAUNCH_TG(1, NHWC);                    \
+    } while (0)
+        if (bd_nhwc) {
+            RROI_LAUNCH_TG_NK(true);
+            return launch_status();  // written in place: no relayout back
+        }
+        RROI_LAUNCH_TG_NK(false);
+#undef RROI_LAUNCH_TG_NK
+#undef RROI_LAUNCH_TG
+        st = launch_status();
+        if (st != 1) return st;
+    } else
     if (gather) {
         // (1) pixel -> (bin, weight) lists: count, scan, fill
         const KeyLayout KL = ws.keys;

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librroi_align_hip.so")
 
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
-PATH_AUTO, PATH_DIRECT, PATH_TILED, PATH_TILED_ATOMIC = 0, 1, 2, 3
+PATH_AUTO, PATH_DIRECT, PATH_TILED, PATH_TILED_ATOMIC, PATH_TILED_LISTS, PATH_TILED_INKERNEL = 0, 1, 2, 3, 4, 5
 STAGE_PROLOGUE, STAGE_GATHER, STAGE_ALL = 1, 2, 3
 
 if not os.path.exists(LIB_PATH):
@@ -188,12 +188,12 @@ def backward(grad_output: torch.Tensor, rois: torch.Tensor, feature_size, spatia
     # the 256 MiB, no relayout pass
     layout = LAYOUT_NCHW
     if (not grad_output.is_contiguous() and grad_output.is_contiguous(memory_format=torch.channels_last)
-            and C % 4 == 0 and path in (PATH_AUTO, PATH_TILED) and R > 0):
+            and C % 4 == 0 and path in (PATH_AUTO, PATH_TILED, PATH_TILED_LISTS, PATH_TILED_INKERNEL) and R > 0):
         layout = LAYOUT_NHWC
     else:
         grad_output = grad_output.contiguous()
     rois = rois.contiguous()
-    cl_grad = bool(channels_last_grad) and C % 4 == 0 and path in (PATH_AUTO, PATH_TILED) and R > 0
+    cl_grad = bool(channels_last_grad) and C % 4 == 0 and path in (PATH_AUTO, PATH_TILED, PATH_TILED_LISTS, PATH_TILED_INKERNEL) and R > 0
     with torch.cuda.device_of(grad_output):
         grad_in = torch.empty((B, C, H, W), dtype=torch.float32, device=grad_output.device,
                               memory_format=torch.channels_last if cl_grad else torch.contiguous_format)

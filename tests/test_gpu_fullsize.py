@@ -72,8 +72,8 @@ def test_cfg3_forward_backward(ext, oracle, full):
     g1 = ext.backward(pooled.detach() * 2, rois, f.shape, 0.25)
     g2 = ext.backward(pooled.detach() * 4, rois, f.shape, 0.25)
     assert torch.allclose(g2, 2 * g1, rtol=1e-4, atol=1e-4 * scale)
-    # direct, tiled (gather) and tiled-atomic (scatter) backward agree
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED_ATOMIC):
+    # direct, both gathers (lists in HBM / lists built in the kernel) and the atomic scatter agree
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
         gd = ext.backward(pooled.detach() * 2, rois, f.shape, 0.25, path=p)
         assert (gd - g1).abs().max().item() <= 1e-4 * scale
 
@@ -113,3 +113,7 @@ def test_cfg4_single_call_4096_rois(ext):
     del out, acc
     gat = ext.backward(g, R, f.shape, 0.25, path=ext.PATH_TILED_ATOMIC)
     assert float((gin - gat).abs().max()) <= 1e-4 * scale
+    del gat
+    # 2.4 GB of relaid-out top_diff fit the in-kernel gather's 32-bit source offsets
+    gik = ext.backward(g, R, f.shape, 0.25, path=ext.PATH_TILED_INKERNEL)
+    assert float((gin - gik).abs().max()) <= 1e-4 * scale

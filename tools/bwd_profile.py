@@ -28,7 +28,8 @@ def call(path):
     assert rc == 1, rc
 
 
-for name, path, n in (("tiled (gather)", ext.PATH_TILED, 50), ("tiled_atomic (scatter)", ext.PATH_TILED_ATOMIC, 20),
+for name, path, n in (("tiled (tile gather)", ext.PATH_TILED, 50), ("tiled_lists (gather over lists in HBM)", ext.PATH_TILED_LISTS, 50),
+                      ("tiled_atomic (scatter)", ext.PATH_TILED_ATOMIC, 20),
                       ("direct", ext.PATH_DIRECT, 5)):
     for _ in range(3):
         call(path)
