@@ -168,7 +168,7 @@ Workspace carve(void* ws, int batch_size, int channels, int height, int width, i
 }
 
 // backward: [affine | chunk-major gradient | pixel counters | pixel offsets | pairs |
-//            chunk-major top_diff (R, nchunks, NB + 1, 32)]
+//            top_diff relaid out to (R, NB, nchunks * 32)]
 struct BwdWorkspace {
     Affine* aff;
     float* gcm;
@@ -200,11 +200,11 @@ BwdWorkspace carve_bwd(void* ws, int batch_size, int channels, int height, int w
     const size_t off_bytes = align_up((nkeys + 1) * sizeof(unsigned), 256);
     const size_t bsum_bytes = align_up((size_t)w.scan_blocks * sizeof(unsigned), 256);
     const size_t pair_bytes = align_up(4 * R * NB * sizeof(uint2), 256);
-    const size_t td_bytes = align_up(R * nchunks * ((size_t)NB + 1) * kLineBytes, 256);
+    const size_t td_bytes = align_up(R * (size_t)NB * nchunks * kLineBytes, 256);   // (R, NB, nchunks * 32)
     // pair slots, top_diff line indices and keys are 32-bit; the gather launches one thread group per key
     // ... and its thread index (key * lanes-per-pixel, at most 64) and block index are 32-bit too
-    w.gather_ok = 4 * R * NB < (1ull << 32) && R * nchunks * ((size_t)NB + 1) < (1ull << 32) &&
-                  nkeys * 64 < (1ull << 32) && nkeys < (1ull << 31);
+    w.gather_ok = 4 * R * NB < (1ull << 32) && R * (size_t)NB < (1ull << 32) &&
+                  (size_t)NB * nchunks * kLineBytes < (1ull << 32) && nkeys * 64 < (1ull << 32) && nkeys < (1ull << 31);
     char* b = reinterpret_cast<char*>(ws);
     w.aff = reinterpret_cast<Affine*>(b);
     b += aff_bytes;
@@ -548,7 +548,7 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
     // 43 / 40, 77 / 62, 201 / 168 -- K3t's serial work per tile is hidden when a lane carries two
     // channel chunks, not when it carries eight.  K3t addresses its source with 32-bit byte offsets.
     const size_t src_bytes = td_nhwc ? (size_t)num_rois * NB * channels * 4
-                                     : (size_t)num_rois * nchunks * ((size_t)NB + 1) * kLineBytes;
+                                     : (size_t)num_rois * NB * nchunks * kLineBytes;
     const bool inkernel_ok = src_bytes < (1ull << 32);
     if (path == RROI_PATH_TILED_INKERNEL && !(gather && inkernel_ok)) return 0;
     const bool lists = path == RROI_PATH_TILED_LISTS || !inkernel_ok ||
@@ -568,10 +568,11 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
     if (gather && !lists) {
         // K3t: relayout of top_diff (one launch, masked bins skipped), then the tile gather
         const KeyLayout KL = ws.keys;
-        const unsigned lines_per_chunk = (unsigned)NB + 1u;
-        const unsigned lines_per_roi = td_nhwc ? (unsigned)NB : lines_per_chunk * (unsigned)nchunks;
-        const unsigned chunk_stride = td_nhwc ? (unsigned)kChunk : lines_per_chunk * (unsigned)kChunk;
-        const unsigned line_stride = td_nhwc ? (unsigned)channels : (unsigned)kChunk;
+        // a list entry names a bin; its chunk k is the 128-byte line at entry * line_stride + k * 32 floats:
+        // in the relaid-out copy (R, NB, nchunks * 32) or in a channels-last top_diff (R, NB, C) consumed in place
+        const unsigned lines_per_roi = (unsigned)NB;
+        const unsigned chunk_stride = (unsigned)kChunk;
+        const unsigned line_stride = td_nhwc ? (unsigned)channels : (unsigned)nchunks * (unsigned)kChunk;
         const FastDiv dnb = make_fastdiv((unsigned)NB), dpw = make_fastdiv((unsigned)pooled_width);
         if (!td_nhwc) {
             const int tt = ceil_div(NB, kRelayoutPx);
@@ -626,12 +627,11 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
         const KeyLayout KL = ws.keys;
         // few scan blocks: every consumer block prefix-sums their totals itself (no second scan launch)
         const int raw_bsum = ws.scan_blocks <= kInlineScanBlocks ? 1 : 0;
-        // list entries name a 32-channel line of top_diff: in the relaid-out copy
-        // (R, nchunks, NB + 1, 32), or in a channels-last top_diff (R, NB, C) consumed in place
-        const unsigned lines_per_chunk = (unsigned)NB + 1u;
-        const unsigned lines_per_roi = td_nhwc ? (unsigned)NB : lines_per_chunk * (unsigned)nchunks;
-        const unsigned chunk_stride = td_nhwc ? (unsigned)kChunk : lines_per_chunk * (unsigned)kChunk;
-        const unsigned line_stride = td_nhwc ? (unsigned)channels : (unsigned)kChunk;
+        // a list entry names a bin; its chunk k is the 128-byte line at entry * line_stride + k * 32 floats:
+        // in the relaid-out copy (R, NB, nchunks * 32) or in a channels-last top_diff (R, NB, C) consumed in place
+        const unsigned lines_per_roi = (unsigned)NB;
+        const unsigned chunk_stride = (unsigned)kChunk;
+        const unsigned line_stride = td_nhwc ? (unsigned)channels : (unsigned)nchunks * (unsigned)kChunk;
         // one pair block per CU, looping over the bins: the pair passes need outstanding atomics,
         // not CU slots -- more blocks only take residency from the relayout (207 -> 197 us per call)
         int pblocks = ceil_div((long)num_rois * NB, 256);
@@ -639,7 +639,7 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
         const FastDiv dnb = make_fastdiv((unsigned)NB), dpw = make_fastdiv((unsigned)pooled_width);
         // count || first half of the relayout;  scan;  fill || second half.  The relayout is the
         // forward's, with R "images" of PH x PW "pixels" and the masked bins skipped:
-        // top_diff (R, C, NB) -> chunk-major (R, nchunks, NB + 1, 32)
+        // top_diff (R, C, NB) -> (R, NB, nchunks * 32)
         const int tt = ceil_div(NB, kRelayoutPx);
         const long tiles = td_nhwc ? 0 : (long)tt * nchunks * num_rois;  // nothing to relay out
         if (tiles >= (1L << 31)) return 0;

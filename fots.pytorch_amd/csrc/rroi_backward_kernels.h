@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
                              div_nb, div_pw, L, cnt, off, bsum, pairs);
         return;
     }
-    relayout_run<SAUX, true>(T, top_diff, tdT, C, NB, pooled_width, pooled_width, div_pw, nchunks, ptiles,
+    relayout_run<SAUX, true, true>(T, top_diff, tdT, C, NB, pooled_width, pooled_width, div_pw, nchunks, ptiles,
                           tile_begin + (int)blockIdx.x - pair_blocks, relayout_blocks, tile_end, aff,
                           batch_size);
 }
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
         const unsigned k = k0 + (sl >> 3);
         const bool c_ok = k < (unsigned)nchunks && k * kChunk + quad * 4u < (unsigned)C;
         // where the 32 channels of chunk k of list entry `line` live: the relaid-out top_diff
-        // (chunk_stride = (NB+1)*32, line_stride = 32) or a channels-last top_diff consumed in
+        // (chunk_stride = 32, line_stride = nchunks * 32) or a channels-last top_diff consumed in
         // place (chunk_stride = 32, line_stride = C), both in floats
         const float* src = tdT + (size_t)k * chunk_stride + quad * 4u;
         v4f acc = z4;

@@ -20,7 +20,11 @@ constexpr int kRelayoutPx = 128;
 // forward masks -- nothing reads them again, so they are neither loaded nor written.
 constexpr int kTP = kRelayoutPx + 4;
 
-template <int AUX, bool MASK>
+// PIXMAJOR: the copy is (image, pixel, nchunks * 32) -- all chunks of a pixel in one nchunks * 128-byte
+// run -- instead of (image, chunk, pixel, 32).  The backward's copy of top_diff uses it: its gather
+// reads the 8 chunks of a bin together, and eight lines of one DRAM page cost less than eight lines 65 KB
+// apart (cfg3: gather 52 -> 39 us).
+template <int AUX, bool MASK, bool PIXMAJOR = false>
 __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float* __restrict__ nchw,
                                                float* __restrict__ cm, int C, int HW, int width, int pitch,
                                                FastDiv div_w, int nchunks, int ptiles, int first_tile,
@@ -105,7 +109,10 @@ __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float*
             const int pt = (cur / nchunks) % ptiles;
             const int b = cur / (ptiles * nchunks);
             const int p0 = pt * kRelayoutPx;
-            float* dst = cm + ((size_t)b * nchunks + k) * slice_stride;
+            const size_t img_bytes = (size_t)HW * nchunks * kLineBytes;   // PIXMAJOR: one image of the copy
+            float* dst = PIXMAJOR ? cm + (size_t)b * (img_bytes / 4) + (size_t)k * kChunk
+                                  : cm + ((size_t)b * nchunks + k) * slice_stride;
+            const unsigned px_floats = PIXMAJOR ? (unsigned)nchunks * kChunk : (unsigned)kChunk;
             const float lim = MASK ? live_limit(b) : 0.0f;
             // wave w writes pixels 32w..32w+31: per instruction 8 pixels x 128 B = 1 KiB contiguous
 #pragma unroll
@@ -119,10 +126,11 @@ __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float*
                 const size_t pix = (size_t)y * pitch + x;
                 if (p0 + p < HW && !(MASK && (float)x > lim)) {
                     if (AUX == 0) {
-                        *reinterpret_cast<v4f*>(dst + pix * kChunk + cq * 4) = v;
+                        *reinterpret_cast<v4f*>(dst + pix * px_floats + cq * 4) = v;
                     } else {
-                        const __amdgpu_buffer_rsrc_t ws = make_rsrc(dst, (unsigned)(slice_stride * 4));
-                        buf_store<AUX>(ws, (unsigned)((pix * kChunk + cq * 4) * 4), v);
+                        const __amdgpu_buffer_rsrc_t ws =
+                            make_rsrc(dst, PIXMAJOR ? (unsigned)(img_bytes - (size_t)k * kLineBytes) : (unsigned)(slice_stride * 4));
+                        buf_store<AUX>(ws, (unsigned)((pix * px_floats + cq * 4) * 4), v);
                     }
                 }
             }
