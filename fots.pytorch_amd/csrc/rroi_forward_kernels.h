@@ -79,7 +79,10 @@ __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float*
             if (c0 + c < C && live) {
                 const float* sp = src + (size_t)c * HW + p;
                 if (vec_ok && p0 + p + 3 < HW) {
-                    v = *reinterpret_cast<const v4f*>(sp);
+                    // PIXMAJOR (the backward's top_diff): read once, streaming -- the copy, not the source,
+                    // should be what the memory-side cache holds when the gather starts
+                    v = PIXMAJOR ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sp))
+                                 : *reinterpret_cast<const v4f*>(sp);
                 } else {
                     if (p0 + p + 0 < HW) v.x = sp[0];
                     if (p0 + p + 1 < HW) v.y = sp[1];
