@@ -578,11 +578,10 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
             const int tt = ceil_div(NB, kRelayoutPx);
             const long tiles = (long)tt * nchunks * num_rois;
             if (tiles >= (1L << 31)) return 0;
-            long unit = nchunks;
-            while (unit % 8) unit += nchunks;
-            long blocks = tiles;
+            // one block per pixel range (all its chunks), at most 8 resident blocks per CU
+            long blocks = tiles / nchunks;
             const long cap = (long)num_cus() * 8;
-            if (blocks > cap) blocks = cap >= unit ? cap / unit * unit : cap;
+            if (blocks > cap) blocks = cap;
 #define RROI_LAUNCH_R(SAUX)                                                                              \
     hipLaunchKernelGGL((rroi_bwd_pairs_relayout_kernel<false, SAUX>), dim3((unsigned)blocks), dim3(256), 0,   \
                        stream, ws.aff, num_rois, height, width, pooled_width, NB, batch_size, lines_per_roi, \
@@ -643,13 +642,11 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
         const int tt = ceil_div(NB, kRelayoutPx);
         const long tiles = td_nhwc ? 0 : (long)tt * nchunks * num_rois;  // nothing to relay out
         if (tiles >= (1L << 31)) return 0;
-        long unit = nchunks;
-        while (unit % 8) unit += nchunks;  // whole groups of chunks per launch and per grid step
+        const long unit = nchunks;  // a block takes all chunks of a pixel range: whole ranges per launch
         const long half = (tiles / 2 + unit - 1) / unit * unit < tiles ? (tiles / 2 + unit - 1) / unit * unit : tiles;
-        auto relayout_grid = [&](long n) {
+        auto relayout_grid = [&](long n) {   // n tiles -> blocks: one per pixel range, at most 8 resident per CU
             const long cap = (long)num_cus() * 8;
-            if (n <= cap) return n;
-            return cap >= unit ? cap / unit * unit : cap;
+            return n / unit <= cap ? n / unit : cap;
         };
 #define RROI_LAUNCH_PR(FILL, SAUX, BLOCKS, T0, T1)                                                   \
     hipLaunchKernelGGL((rroi_bwd_pairs_relayout_kernel<FILL, SAUX>), dim3((unsigned)(pblocks + (BLOCKS))), \

@@ -143,9 +143,10 @@ __global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
                              div_nb, div_pw, L, cnt, off, bsum, pairs);
         return;
     }
+    // block j takes the pixel ranges j, j + blocks, ... of [tile_begin, tile_end), all chunks of each
     relayout_run<SAUX, true, true>(T, top_diff, tdT, C, NB, pooled_width, pooled_width, div_pw, nchunks, ptiles,
-                          tile_begin + (int)blockIdx.x - pair_blocks, relayout_blocks, tile_end, aff,
-                          batch_size);
+                          tile_begin + ((int)blockIdx.x - pair_blocks) * nchunks, relayout_blocks * nchunks, tile_end,
+                          aff, batch_size);
 }
 
 // Exclusive scan of cnt[0..N) (N = keys + 1, the last element reads as 0), two levels:

@@ -95,7 +95,13 @@ __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float*
     };
     // grid-stride over tiles, software-pipelined: the loads of the next tile are in flight
     // while the current tile goes through LDS and out to the chunk-major copy
+    // PIXMAJOR: a block takes the nchunks tiles of one pixel range one after the other (first_tile and
+    // tile_stride are multiples of nchunks), so that what it writes is one contiguous run of the copy
     int tile = first_tile;
+    auto advance = [&](int t) {
+        if (!PIXMAJOR) return t + tile_stride;
+        return (t + 1) % nchunks ? t + 1 : t + 1 - nchunks + tile_stride;
+    };
     if (tile < relayout_tiles) load_tile(tile);
     while (tile < relayout_tiles) {
 #pragma unroll
@@ -105,7 +111,7 @@ __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float*
         }
         __syncthreads();
         const int cur = tile;
-        tile += tile_stride;
+        tile = advance(tile);
         if (tile < relayout_tiles) load_tile(tile);
         {
             const int k = cur % nchunks;
