@@ -143,6 +143,22 @@ FastDiv make_fastdiv(unsigned d)
     return f;
 }
 
+PatchMap make_patch_map(int pooled_height, int pooled_width)
+{
+    unsigned pr = 1;   // rows of a patch: the largest power of two <= min(PH, 8)
+    while (pr * 2 <= (unsigned)pooled_height && pr * 2 <= 8u) pr *= 2;
+    PatchMap pm;
+    pm.pc_shift = 0;
+    while ((64u >> pm.pc_shift) > pr) ++pm.pc_shift;   // 64 / pr columns
+    const unsigned pc = 1u << pm.pc_shift;
+    const unsigned npy = ((unsigned)pooled_height + pr - 1) / pr;
+    pm.npx = ((unsigned)pooled_width + pc - 1) / pc;
+    pm.lanes_per_roi = npy * pm.npx * 64u;
+    pm.div_roi = make_fastdiv(pm.lanes_per_roi);
+    pm.div_npx = make_fastdiv(pm.npx);
+    return pm;
+}
+
 struct Workspace {
     Affine* aff;
     float* cm;
@@ -573,7 +589,8 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
         const unsigned lines_per_roi = (unsigned)NB;
         const unsigned chunk_stride = (unsigned)kChunk;
         const unsigned line_stride = td_nhwc ? (unsigned)channels : (unsigned)nchunks * (unsigned)kChunk;
-        const FastDiv dnb = make_fastdiv((unsigned)NB), dpw = make_fastdiv((unsigned)pooled_width);
+        const FastDiv dpw = make_fastdiv((unsigned)pooled_width);
+        const PatchMap dnb = make_patch_map(pooled_height, pooled_width);
         if (!td_nhwc) {
             const int tt = ceil_div(NB, kRelayoutPx);
             const long tiles = (long)tt * nchunks * num_rois;
@@ -633,9 +650,11 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
         const unsigned line_stride = td_nhwc ? (unsigned)channels : (unsigned)nchunks * (unsigned)kChunk;
         // one pair block per CU, looping over the bins: the pair passes need outstanding atomics,
         // not CU slots -- more blocks only take residency from the relayout (207 -> 197 us per call)
-        int pblocks = ceil_div((long)num_rois * NB, 256);
+        const FastDiv dpw = make_fastdiv((unsigned)pooled_width);
+        const PatchMap dnb = make_patch_map(pooled_height, pooled_width);
+        if ((long)num_rois * dnb.lanes_per_roi >= (1L << 32)) return 0;
+        int pblocks = ceil_div((long)num_rois * dnb.lanes_per_roi, 256);
         if (pblocks > num_cus()) pblocks = num_cus();
-        const FastDiv dnb = make_fastdiv((unsigned)NB), dpw = make_fastdiv((unsigned)pooled_width);
         // count || first half of the relayout;  scan;  fill || second half.  The relayout is the
         // forward's, with R "images" of PH x PW "pixels" and the masked bins skipped:
         // top_diff (R, C, NB) -> (R, NB, nchunks * 32)

@@ -94,28 +94,44 @@ __device__ __forceinline__ const unsigned* block_prefix(const unsigned* __restri
     return lds;
 }
 
+// Thread -> bin of the pair passes: the 64 lanes of a wave take a PATCH of the bin grid (8 pooled rows x
+// 8 columns when PH >= 8), not 64 consecutive bins of one row.  The atomics of the passes are bound by the
+// number of 128-byte counter lines an instruction touches; a square patch of bins lands in half as many
+// 8 x 4-pixel key tiles as a 64-bin row segment.
+struct PatchMap {
+    FastDiv div_roi;        // / lanes per ROI
+    FastDiv div_npx;        // / patches per pooled row band
+    unsigned lanes_per_roi; // npy * npx * 64
+    unsigned npx;
+    unsigned pc_shift;      // log2(columns of a patch); rows of a patch = 64 >> pc_shift
+};
+
 // FILL == false: cnt[key] += 1 per pair.  FILL == true: cnt counts back down, handing out the
 // slots of the key's segment.
 template <bool FILL>
 __device__ __forceinline__ void pairs_body(unsigned idx, const Affine* __restrict__ aff, int num_rois,
-                                           int height, int width, int pooled_width, int NB, int batch_size,
-                                           unsigned lines_per_roi, FastDiv div_nb, FastDiv div_pw,
+                                           int height, int width, int pooled_height, int pooled_width, int batch_size,
+                                           unsigned lines_per_roi, const PatchMap& pm,
                                            const KeyLayout& L, int* __restrict__ cnt,
                                            const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
                                            uint2* __restrict__ pairs)
 {
-    const unsigned n = fdiv(idx, div_nb);
+    const unsigned n = fdiv(idx, pm.div_roi);
     if (n >= (unsigned)num_rois) return;
-    const unsigned j = idx - n * (unsigned)NB;
-    const unsigned ph = fdiv(j, div_pw);
-    const unsigned pw = j - ph * (unsigned)pooled_width;
+    const unsigned rem = idx - n * pm.lanes_per_roi;
+    const unsigned patch = rem >> 6, l = rem & 63u;
+    const unsigned py = fdiv(patch, pm.div_npx), px = patch - py * pm.npx;
+    const unsigned ph = py * (64u >> pm.pc_shift) + (l >> pm.pc_shift);
+    const unsigned pw = (px << pm.pc_shift) + (l & ((1u << pm.pc_shift) - 1u));
+    if (ph >= (unsigned)pooled_height || pw >= (unsigned)pooled_width) return;
+    const unsigned j = ph * (unsigned)pooled_width + pw;
     const Affine A = aff[n];
     bin_pairs(A, ph, pw, height, width, batch_size, L, [&](unsigned key, float w) {
         if (!FILL) {
             atomicAdd(cnt + key, 1);
         } else {
             const int slot = atomicAdd(cnt + key, -1) - 1;
-            // line index of (roi n, bin j) in chunk 0 of the relaid-out top_diff
+            // line index of (roi n, bin j) in the relaid-out top_diff
             pairs[list_offset(off, bsum, key) + (unsigned)slot] = make_uint2(n * lines_per_roi + j, as_u(w));
         }
     });
@@ -128,7 +144,7 @@ __device__ __forceinline__ void pairs_body(unsigned idx, const Affine* __restric
 template <bool FILL, int SAUX>
 __global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
     const Affine* __restrict__ aff, int num_rois, int height, int width, int pooled_width, int NB,
-    int batch_size, unsigned lines_per_roi, FastDiv div_nb, FastDiv div_pw, KeyLayout L,
+    int batch_size, unsigned lines_per_roi, PatchMap pm, FastDiv div_pw, KeyLayout L,
     int* __restrict__ cnt, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
     uint2* __restrict__ pairs, int pair_blocks, const float* __restrict__ top_diff,
     float* __restrict__ tdT, int C, int nchunks, int ptiles, int relayout_blocks, int tile_begin,
@@ -137,10 +153,10 @@ __global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
     if ((int)blockIdx.x < pair_blocks) {
         if (FILL) bsum = block_prefix(bsum, scan_blocks, raw_bsum != 0, reinterpret_cast<unsigned*>(T));
-        const unsigned total = (unsigned)num_rois * (unsigned)NB;
+        const unsigned total = (unsigned)num_rois * pm.lanes_per_roi;
         for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += (unsigned)pair_blocks * 256u)
-            pairs_body<FILL>(idx, aff, num_rois, height, width, pooled_width, NB, batch_size, lines_per_roi,
-                             div_nb, div_pw, L, cnt, off, bsum, pairs);
+            pairs_body<FILL>(idx, aff, num_rois, height, width, NB / pooled_width, pooled_width, batch_size,
+                             lines_per_roi, pm, L, cnt, off, bsum, pairs);
         return;
     }
     // block j takes the pixel ranges j, j + blocks, ... of [tile_begin, tile_end), all chunks of each
