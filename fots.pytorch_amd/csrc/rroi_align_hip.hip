@@ -264,6 +264,9 @@ bool pick_tiled_bwd(int batch_size, int channels, int height, int width, int num
 
 int g_store_aux = 2;   // cache policy of the output stores (see buf_store); 16 / 0 for exploration
 int g_fwd_dbg = 0;     // ablation: 1 = skip output stores, 2 = all taps out of range
+#ifdef RROI_EXPLORE
+int g_fwd_early = 2;   // exploration: LO groups issued ahead of the stores (template parameter EARLY)
+#endif
 int g_prologue_blocks_per_cu = 3;
 int g_prologue_aux = 0;
 // store policy of the backward's top_diff relayout (tools/bwd_profile.py with RROI_BWD_SWEEP=1, four
@@ -443,6 +446,17 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         else if (g_store_aux == 0) RROI_LAUNCH_FWD(true, 0);    // exploration only
         else if (g_store_aux == 16) RROI_LAUNCH_FWD(true, 16);  // exploration only
         else if (g_store_aux == 3) RROI_LAUNCH_FWD(true, 3);    // exploration only: pure nt (sc0 nt)
+#ifdef RROI_EXPLORE
+#define RROI_LAUNCH_FWD_E(E)                                                                              \
+    hipLaunchKernelGGL((rroi_fwd_tiled_kernel<true, 2, false, E>), dim3(grid), dim3(kWave), 0, stream, map, \
+                       ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,     \
+                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
+        else if (g_fwd_early == 1) RROI_LAUNCH_FWD_E(1);
+        else if (g_fwd_early == 3) RROI_LAUNCH_FWD_E(3);
+        else if (g_fwd_early == 4) RROI_LAUNCH_FWD_E(4);
+        else if (g_fwd_early == 5) RROI_LAUNCH_FWD_E(5);
+#undef RROI_LAUNCH_FWD_E
+#endif
         else RROI_LAUNCH_FWD(true, 2);
 #undef RROI_LAUNCH_FWD
     }
@@ -469,6 +483,12 @@ int rroi_align_debug_set_fwd_dbg(int v)
 {
     const int old = g_fwd_dbg;
     g_fwd_dbg = v;
+    return old;
+}
+int rroi_align_debug_set_fwd_early(int v)
+{
+    const int old = g_fwd_early;
+    g_fwd_early = v;
     return old;
 }
 int rroi_align_debug_set_prologue_blocks(int v)

@@ -198,7 +198,7 @@ __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois,
 // The three phases of consecutive items are interleaved around the store burst, see the
 // loop at the end.
 // ------------------------------------------------------------------------------------
-template <bool VEC_STORE, int AUX, bool ONHWC = false>
+template <bool VEC_STORE, int AUX, bool ONHWC = false, int EARLY = 2>
 __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
@@ -216,6 +216,10 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     // two classes, each padded to a multiple of 8: ceil(a/8) + ceil(b/8) <= 9 for a + b <= 64 (and one
     // forced LO group + 8 HI groups when a = 0)
     constexpr int kMaxGroups = kIters + 1;
+    // LO groups whose loads are issued ahead of the previous tile's stores.  A/B in one process (tools/kbench
+    // early, three rounds): 1 group 46.1-47.2 us kernel / 53.85 us step, 2 groups 45.45 / 53.45, 3 45.7 / 53.65,
+    // 4 46.4 / 53.9, 5 47.3 / 54.75
+    constexpr int kEarly = EARLY;
     constexpr unsigned kPadPos = kTileBins;  // "bin position" of a padding record
     // T: rows 0..31 are the tile; the tail absorbs the writes of padding records (4 rows at the
     // tile's pitch, 32 columns: 32 different banks).  LDS is granted in 1280-byte granules on gfx950;
@@ -312,9 +316,11 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
             HP[pidx] = (unsigned char)kPadPos;
         }
     };
-    uint4 ra[2];
+    // register sets 0 / 1: the depth-2 pipeline of phase B; sets 2 .. 2 + kEarly - 1: the first LO groups of
+    // an item, whose loads go out BEFORE the previous tile's stores (see the loop at the end)
+    uint4 ra[2 + kEarly];
     unsigned hpos[2];
-    v4f lt[2], rt[2], lb[2], rbv[2];
+    v4f lt[2 + kEarly], rt[2 + kEarly], lb[2], rbv[2];
     auto fetch_lo = [&](unsigned p, unsigned grp, int s) { ra[s] = Gbuf[p * kRecs + grp * kBinsPerIter + b]; };
     auto fetch_hi = [&](unsigned p, unsigned grp, int s) {
         ra[s] = Gbuf[p * kRecs + grp * kBinsPerIter + b];
@@ -479,30 +485,49 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
         const bool batch_ok = batch >= 0 && batch < batch_size;
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(
             map + (size_t)(batch_ok ? batch : 0) * lay.img_stride + (size_t)k * lay.chunk_stride, lay.slice_bytes);
-        fetch_lo(p, 0, 0);
-        issue_lo(rs, 0);  // LO group 0 (there always is one)
+        // the first kEarly LO groups go out ahead of the stores, unconditionally (a record beyond the
+        // item's LO groups is a HI record, padding or stale: its offsets are in range or kOOB, the
+        // data is never used) -- straight-line code keeps the s_waitcnt counts exact
+#pragma unroll
+        for (int e = 0; e < kEarly; ++e) {
+            fetch_lo(p, e, 2 + e);
+            issue_lo(rs, 2 + e);
+        }
         store_tile(n_prev, t_prev, mask_prev, have_prev);
         lds_wave_sync();  // T has been read: free for this item's blends
         if (has_next) geometry(A_next, t_next, p ^ 1u, g_lo_next, g_hi_next, mask_next);
 
-        // ---- phase B: LO groups (group 0 is already in flight), then HI groups; the loads of
-        // group g+1 are issued before group g is blended.  The loops are unrolled with an early
-        // exit, and the two exit paths end in different (empty) asm statements so that the
-        // compiler cannot merge their tails: each blend then has ONE predecessor and its
-        // s_waitcnt knows exactly how many younger loads are in flight.
+        // ---- phase B.  The early groups are blended first: their loads are OLDER than the stores, so
+        // they need no store acknowledgement; the next group's loads go out before that (again
+        // unconditionally).  Then the remaining LO groups and the HI groups; the loads of group g+1 are
+        // issued before group g is blended.  The loops are unrolled with an early exit, and the two
+        // exit paths end in different (empty) asm statements so that the compiler cannot merge their
+        // tails: each blend then has ONE predecessor and its s_waitcnt knows exactly how many younger
+        // loads are in flight.
+        fetch_lo(p, kEarly, 0);
+        issue_lo(rs, 0);
 #pragma unroll
-        for (int it = 0; it < kIters; ++it) {
-            const int s = it & 1;
-            if ((unsigned)(it + 1) < g_lo) {
-                fetch_lo(p, it + 1, s ^ 1);
-                issue_lo(rs, s ^ 1);
-                pin_lo(s);
-                blend_lo(s);
-                asm volatile("; lo: more groups follow");
-            } else {
-                blend_lo(s);
-                asm volatile("; lo: last group");
-                break;
+        for (int e = 0; e < kEarly; ++e) {
+            if ((unsigned)e < g_lo) {
+                pin_lo(2 + e);
+                blend_lo(2 + e);
+            }
+        }
+        if (g_lo > (unsigned)kEarly) {
+#pragma unroll
+            for (int it = kEarly; it < kMaxGroups; ++it) {
+                const int s = (it - kEarly) & 1;
+                if ((unsigned)(it + 1) < g_lo) {
+                    fetch_lo(p, it + 1, s ^ 1);
+                    issue_lo(rs, s ^ 1);
+                    pin_lo(s);
+                    blend_lo(s);
+                    asm volatile("; lo: more groups follow");
+                } else {
+                    blend_lo(s);
+                    asm volatile("; lo: last group");
+                    break;
+                }
             }
         }
         if (g_hi > 0) {

@@ -128,6 +128,33 @@ __global__ __launch_bounds__(64) void k_store_aux(float* __restrict__ out, int n
     }
 }
 
+// ---- store-only, the shipped policy mix (one store of eight sc0 sc1, seven nt), two address patterns:
+// PATTERN 0 = the product's tile (a wave writes 32 row segments of 256 B, 2 KiB apart);
+// PATTERN 1 = what 8 waves that share a (roi, chunk) block in LDS could write: a wave writes 4 whole
+//             rows = 8 KiB contiguous, every instruction 1 KiB contiguous.
+template <int PATTERN, int MINOR>
+__global__ __launch_bounds__(64) void k_store_mix(float* __restrict__ out, int nchunks, int ntiles)
+{
+    const unsigned lane = threadIdx.x;
+    const unsigned k = blockIdx.x % nchunks, slot = blockIdx.x / nchunks, nslots = gridDim.x / nchunks;
+    const unsigned items = R * ntiles;
+    const unsigned col = (lane & 15) * 4, row0 = lane >> 4;
+    const v4u v = {1u, 2u, 3u, lane};
+    for (unsigned item = slot; item < items; item += nslots) {
+        const unsigned n = item / ntiles, t = item % ntiles;
+        float* obase = out + ((size_t)n * C + k * 32) * NB;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, 32u * NB * 4u);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            unsigned off;
+            if (PATTERN == 0) off = ((s * 4 + row0) * NB + t * 64 + col) * 4u;
+            else off = t * 8192u + s * 1024u + lane * 16u;
+            if (s < MINOR) __builtin_amdgcn_raw_buffer_store_b128(v, ws, off, 0, 17);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, ws, off, 0, 2);
+        }
+    }
+}
+
 // ---- TA instruction rate: buffer_load_dwordx4 in a 16 KiB (L1-resident) window; a fraction of
 // the 8-lane groups is out of range (MODE 0: none, 1: half, 2: 7/8, 3: all) or exec-masked
 // (MODE 4: half masked by a branch). 8 independent loads in flight.
@@ -284,6 +311,48 @@ int main(int argc, char** argv)
             hipLaunchKernelGGL(k_store_tile<1>, dim3(4096), dim3(64), 0, 0, out, 8, 8);
             CK(hipMemsetAsync(out, 0, out_elems * 4, 0));
             CK(hipDeviceSynchronize());
+        }
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "early") {
+        // A/B over the number of LO groups whose loads go out ahead of the previous tile's stores
+        auto stage = [&](int s) {
+            int rc = rroi_align_forward_stages_hip(feat, 0, 0.25f, 1, R, H, W, C, PH, PW, rois_d, out, ws, wsb, 2, s, 0);
+            if (rc != 1) { fprintf(stderr, "stage rc=%d\n", rc); exit(1); }
+        };
+        for (int i = 0; i < 300; ++i) stage(3);
+        CK(hipDeviceSynchronize());
+        for (int rep = 0; rep < 3; ++rep)
+            for (int e : {1, 2, 3, 4, 5}) {
+                rroi_align_debug_set_fwd_early(e);
+                char nm[96];
+                snprintf(nm, 96, "rep %d early=%d: gather alone (200 launches)", rep, e);
+                report(nm, T.us([&] { stage(2); }, 200, 20), MB);
+                snprintf(nm, 96, "rep %d early=%d: whole step, 50 x 20 steps", rep, e);
+                report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 50, 5) / 20, MB);
+            }
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "stmix") {
+        // store-only kernels with the shipped policy mix, two address patterns; alone and followed by the
+        // product's prologue (what the write stream does to the next call's relayout)
+        auto stage = [&](int s) {
+            int rc = rroi_align_forward_stages_hip(feat, 0, 0.25f, 1, R, H, W, C, PH, PW, rois_d, out, ws, wsb, 2, s, 0);
+            if (rc != 1) { fprintf(stderr, "stage rc=%d\n", rc); exit(1); }
+        };
+        for (int i = 0; i < 300; ++i) stage(3);
+        CK(hipDeviceSynchronize());
+        for (int rep = 0; rep < 2; ++rep) {
+            report("tile pattern, 1/8 sc0sc1 + nt", T.us([&] { hipLaunchKernelGGL((k_store_mix<0, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 8); }, 100), MB);
+            report("8 KiB contiguous per wave, 1/8 sc0sc1 + nt", T.us([&] { hipLaunchKernelGGL((k_store_mix<1, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 8); }, 100), MB);
+            report("tile pattern, pure nt", T.us([&] { hipLaunchKernelGGL((k_store_mix<0, 0>), dim3(3072), dim3(64), 0, 0, out, 8, 8); }, 100), MB);
+            report("8 KiB contiguous per wave, pure nt", T.us([&] { hipLaunchKernelGGL((k_store_mix<1, 0>), dim3(3072), dim3(64), 0, 0, out, 8, 8); }, 100), MB);
+            report("tile pattern, 2/8 sc0sc1 + nt", T.us([&] { hipLaunchKernelGGL((k_store_mix<0, 2>), dim3(3072), dim3(64), 0, 0, out, 8, 8); }, 100), MB);
+            report("8 KiB contiguous per wave, 2/8 sc0sc1 + nt", T.us([&] { hipLaunchKernelGGL((k_store_mix<1, 2>), dim3(3072), dim3(64), 0, 0, out, 8, 8); }, 100), MB);
+            report("  step: prologue + tile pattern 1/8", T.us([&] { for (int i = 0; i < 20; ++i) { stage(1); hipLaunchKernelGGL((k_store_mix<0, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 8); } }, 20, 3) / 20, MB);
+            report("  step: prologue + 8 KiB contiguous 1/8", T.us([&] { for (int i = 0; i < 20; ++i) { stage(1); hipLaunchKernelGGL((k_store_mix<1, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 8); } }, 20, 3) / 20, MB);
+            report("  step: prologue + 8 KiB contiguous 2/8", T.us([&] { for (int i = 0; i < 20; ++i) { stage(1); hipLaunchKernelGGL((k_store_mix<1, 2>), dim3(3072), dim3(64), 0, 0, out, 8, 8); } }, 20, 3) / 20, MB);
+            report("  step: product (prologue + gather)", T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 20, 3) / 20, MB);
         }
         return 0;
     }
