@@ -265,6 +265,7 @@ bool pick_tiled_bwd(int batch_size, int channels, int height, int width, int num
 int g_store_aux = 2;   // cache policy of the output stores (see buf_store); 16 / 0 for exploration
 int g_fwd_dbg = 0;     // ablation: 1 = skip output stores, 2 = all taps out of range
 #ifdef RROI_EXPLORE
+int g_fwd_minor = 1;   // exploration: write-through stores per tile (template parameter MINOR)
 int g_fwd_early = 2;   // exploration: LO groups issued ahead of the stores (template parameter EARLY)
 #endif
 int g_prologue_blocks_per_cu = 3;
@@ -451,6 +452,14 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     hipLaunchKernelGGL((rroi_fwd_tiled_kernel<true, 2, false, E>), dim3(grid), dim3(kWave), 0, stream, map, \
                        ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,     \
                        nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
+#define RROI_LAUNCH_FWD_M(M)                                                                              \
+    hipLaunchKernelGGL((rroi_fwd_tiled_kernel<true, 2, false, 2, M>), dim3(grid), dim3(kWave), 0, stream, map, \
+                       ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,     \
+                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
+        else if (g_fwd_minor == 2) RROI_LAUNCH_FWD_M(2);
+        else if (g_fwd_minor == 3) RROI_LAUNCH_FWD_M(3);
+        else if (g_fwd_minor == 4) RROI_LAUNCH_FWD_M(4);
+#undef RROI_LAUNCH_FWD_M
         else if (g_fwd_early == 1) RROI_LAUNCH_FWD_E(1);
         else if (g_fwd_early == 3) RROI_LAUNCH_FWD_E(3);
         else if (g_fwd_early == 4) RROI_LAUNCH_FWD_E(4);
@@ -483,6 +492,12 @@ int rroi_align_debug_set_fwd_dbg(int v)
 {
     const int old = g_fwd_dbg;
     g_fwd_dbg = v;
+    return old;
+}
+int rroi_align_debug_set_fwd_minor(int v)
+{
+    const int old = g_fwd_minor;
+    g_fwd_minor = v;
     return old;
 }
 int rroi_align_debug_set_fwd_early(int v)

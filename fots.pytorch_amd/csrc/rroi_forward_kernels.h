@@ -198,7 +198,7 @@ __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois,
 // The three phases of consecutive items are interleaved around the store burst, see the
 // loop at the end.
 // ------------------------------------------------------------------------------------
-template <bool VEC_STORE, int AUX, bool ONHWC = false, int EARLY = 2>
+template <bool VEC_STORE, int AUX, bool ONHWC = false, int EARLY = 2, int MINOR = 1>
 __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
                 if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
                     // AUX == 2 (the shipped policy): the first of the tile's eight stores goes out
                     // write-through (sc0 sc1), the other seven streaming (nt) -- see buf_store
-                    if (AUX == 2 && hs == 0 && s4 == 0)
+                    if (AUX == 2 && hs * (kChunk / 8) + s4 < MINOR)
                         buf_store<kMinorAux>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);
                     else
                     buf_store<AUX>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);

@@ -412,11 +412,15 @@ int main(int argc, char** argv)
             CK(hipMemcpy(rois_d, pr.data(), pr.size() * 4, hipMemcpyHostToDevice));
             const char* nm4[4] = {"as generated", "sorted by centre y", "sorted by Morton code of the centre (8 px cells)", "32-row bands, x inside"};
             char nm[128];
-            stage(3);
-            snprintf(nm, 128, "gather, ROIs %s", nm4[mode]);
-            report(nm, T.us([&] { stage(2); }, 200, 20), MB);
-            snprintf(nm, 128, "  whole step, ROIs %s", nm4[mode]);
-            report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 50, 5) / 20, MB);
+            for (int minor : {1, 2, 3}) {   // write-through stores per tile: a sorted order leaves the L2 more room
+                rroi_align_debug_set_fwd_minor(minor);
+                stage(3);
+                snprintf(nm, 128, "gather, %d/8 write-through, ROIs %s", minor, nm4[mode]);
+                report(nm, T.us([&] { stage(2); }, 200, 20), MB);
+                snprintf(nm, 128, "  whole step, %d/8 write-through, ROIs %s", minor, nm4[mode]);
+                report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 50, 5) / 20, MB);
+            }
+            rroi_align_debug_set_fwd_minor(1);
         }
         return 0;
     }
