@@ -314,6 +314,29 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    if (argc > 1 && std::string(argv[1]) == "ablstep") {
+        // the ablations of the gather kernel INSIDE the step (prologue + gather, 20 back-to-back): dbg bit 0 =
+        // output stores dropped by the descriptor check, bit 1 = every tap out of range (no map reads)
+        auto stage = [&](int s) {
+            int rc = rroi_align_forward_stages_hip(feat, 0, 0.25f, 1, R, H, W, C, PH, PW, rois_d, out, ws, wsb, 2, s, 0);
+            if (rc != 1) { fprintf(stderr, "stage rc=%d\n", rc); exit(1); }
+        };
+        for (int i = 0; i < 300; ++i) stage(3);
+        CK(hipDeviceSynchronize());
+        for (int rep = 0; rep < 2; ++rep)
+            for (int dbg : {0, 1, 2, 3}) {
+                rroi_align_debug_set_fwd_dbg(dbg);
+                char nm[96];
+                snprintf(nm, 96, "ablation=%d: gather alone", dbg);
+                report(nm, T.us([&] { stage(2); }, 200, 20), MB);
+                snprintf(nm, 96, "ablation=%d: whole step", dbg);
+                report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 50, 5) / 20, MB);
+            }
+        rroi_align_debug_set_fwd_dbg(0);
+        report("prologue alone, 20 back-to-back", T.us([&] { for (int i = 0; i < 20; ++i) stage(1); }, 50, 5) / 20, 52.4);
+        report("  step: prologue + store-only tile pattern 1/8", T.us([&] { for (int i = 0; i < 20; ++i) { stage(1); hipLaunchKernelGGL((k_store_mix<0, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 8); } }, 50, 5) / 20, MB);
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "early") {
         // A/B over the number of LO groups whose loads go out ahead of the previous tile's stores
         auto stage = [&](int s) {
