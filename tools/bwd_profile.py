@@ -28,7 +28,12 @@ def call(path):
     assert rc == 1, rc
 
 
-for name, path, n in (("tiled (tile gather)", ext.PATH_TILED, 50), ("tiled_lists (gather over lists in HBM)", ext.PATH_TILED_LISTS, 50),
+if os.environ.get("RROI_BWD_ONLY"):   # the default path alone (for counter passes: one kind of launch per kernel name)
+    for _ in range(30):
+        call(ext.PATH_TILED)
+    torch.cuda.synchronize()
+    sys.exit(0)
+for name, path, n in (("tiled (default: lists in HBM for C > 64)", ext.PATH_TILED, 50), ("tiled_inkernel (lists built in the gather kernel)", ext.PATH_TILED_INKERNEL, 50),
                       ("tiled_atomic (scatter)", ext.PATH_TILED_ATOMIC, 20),
                       ("direct", ext.PATH_DIRECT, 5)):
     for _ in range(3):
