@@ -165,6 +165,28 @@ def test_backward_edge_rois(ext, oracle):
         assert np.abs(got - want).max() <= BWD_RTOL * max(1.0, float(np.abs(want).max()))
 
 
+def test_backward_heavy_overlap(ext, oracle):
+    """Hundreds of ROIs on the same few pixels: lists of thousands of pairs per pixel, more than 256
+    candidate ROIs and more than 512 row segments per map tile (the in-kernel gather processes them in
+    several ROI batches, segment flushes and rounds), two images, tall pooled grids."""
+    rng = np.random.default_rng(77)
+    for (R, C, H, W, ph, pw, B) in ((600, 8, 24, 40, 8, 24, 1), (300, 36, 16, 16, 16, 9, 2)):
+        f = rng.standard_normal((B, C, H, W), dtype=np.float32)
+        rois = np.zeros((R, 6), np.float32)
+        rois[:, 0] = rng.integers(0, B, R)
+        rois[:, 1] = (W / 2 + rng.uniform(-3, 3, R)) * 4
+        rois[:, 2] = (H / 2 + rng.uniform(-3, 3, R)) * 4
+        rois[:, 3] = rng.uniform(8, 40, R)
+        rois[:, 4] = rois[:, 3] * rng.uniform(1, 4, R)
+        rois[:, 5] = rng.uniform(-90, 90, R)
+        rois[: R // 3] = rois[0]                      # identical copies
+        gout = rng.standard_normal((R, C, ph, pw), dtype=np.float32)
+        want = oracle.backward_c(gout, rois, f.shape, 0.25)
+        for p in (ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
+            got = ext.backward(dev(gout), dev(rois), f.shape, 0.25, path=p).cpu().numpy()
+            assert np.abs(got - want).max() <= BWD_RTOL * max(1.0, float(np.abs(want).max())), (R, p)
+
+
 def test_more_than_256_channels(ext, oracle):
     """C = 300: ten channel chunks -- the forward's chunk loop leaves the one-chunk-per-XCD regime
     and the gather backward needs a second channel pass (64 lanes cover 8 chunks)."""
