@@ -602,8 +602,12 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
                                      : (size_t)num_rois * NB * nchunks * kLineBytes;
     const bool inkernel_ok = src_bytes < (1ull << 32);
     if (path == RROI_PATH_TILED_INKERNEL && !(gather && inkernel_ok)) return 0;
+    // ... with four chunks per lane (C <= 128) it still wins where the lists are short: C = 128, 160x160,
+    // 8x64: R = 32 33 / 42, 128 48 / 48, 512 101 / 93;  C = 96, 176x320, 11x96: 38 / 45, 56 / 61, 114 / 122
+    const bool short_lists = (double)num_rois * NB <= 8.0 * (double)batch_size * HW;   // bins per map pixel
+    const bool prefer_inkernel = nchunks <= 2 || (nchunks <= 4 && short_lists);
     const bool lists = path == RROI_PATH_TILED_LISTS || !inkernel_ok ||
-                       (path != RROI_PATH_TILED_INKERNEL && nchunks > 2);
+                       (path != RROI_PATH_TILED_INKERNEL && !prefer_inkernel);
     {
         // affine table; the list passes' pixel counters (K3g) are cleared by the same launch
         const unsigned nzero = gather && lists ? ws.keys.keys : 0u;

@@ -70,9 +70,11 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
 #define RROI_PATH_TILED_ATOMIC 3 /* backward only: the tiled scatter with fp32 atomics (the
                                     default tiled backward is an atomic-free gather)         */
 #define RROI_PATH_TILED_LISTS 4  /* backward only: the gather over per-pixel lists built in HBM by
-                                    count / scan / fill launches (what TILED runs for C > 64)  */
+                                    count / scan / fill launches (what TILED runs for C > 128,
+                                    and for C > 64 when the lists are long)                  */
 #define RROI_PATH_TILED_INKERNEL 5 /* backward only: the gather that finds each map tile's bins
-                                    inside the kernel (what TILED runs for C <= 64)           */
+                                    inside the kernel (what TILED runs for C <= 64, and for C <= 128
+                                    while there are at most 8 bins per map pixel)            */
 
 /* Bytes of scratch the tiled path needs for this problem (0 for the direct
  * path).  The caller owns the scratch; its contents are dead after the call. */
