@@ -371,6 +371,10 @@ def run(args):
                 "what": "configs[2]: grad w.r.t. the features, same shapes, rroi_align_backward_hip (gather path), "
                         "50 back-to-back calls; not part of `value`",
                 "ms_per_call": round(bwd_ms, 5),
+                # grad_out read + grad_in write (+ rois) over the whole call, against the same peak
+                "algorithmic_bytes": int(R * c["C"] * c["PH"] * c["PW"] * 4 + c["C"] * c["H"] * c["W"] * 4 + R * 24),
+                "frac_of_peak_whole_call": round((R * c["C"] * c["PH"] * c["PW"] * 4 + c["C"] * c["H"] * c["W"] * 4 + R * 24)
+                                                 / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "ms_per_call_channels_last": round(bwd_cl_ms, 5)},  # top_diff and the feature gradient both channels_last
             "e2e": e2e,
         },
