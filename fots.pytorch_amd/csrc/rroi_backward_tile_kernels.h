@@ -1,4 +1,4 @@
-// rroi_backward_tile_kernels.h -- backward gather with the pixel lists built INSIDE the kernel (K3t, the default tiled backward)
+// rroi_backward_tile_kernels.h -- backward gather with the pixel lists built INSIDE the kernel (K3t: the tiled backward for C <= 64, and for C <= 128 while the lists are short)
 // Part of the single translation unit rroi_align_hip.hip (included inside its anonymous
 // namespace after rroi_backward_kernels.h); not a standalone header.
 #pragma once
