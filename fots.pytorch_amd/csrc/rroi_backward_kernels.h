@@ -274,34 +274,58 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
         // (chunk_stride = 32, line_stride = nchunks * 32) or a channels-last top_diff consumed in
         // place (chunk_stride = 32, line_stride = C), both in floats
         const float* src = tdT + (size_t)k * chunk_stride + quad * 4u;
-        v4f acc = z4;
         // The walk is a chain of dependent memory round trips (offsets -> records -> data), and
         // the kernel is bound by that chain, not by bytes.  So the records are fetched `sub` at a
         // time -- lane j of the group loads record j, one coalesced access -- and handed round
         // with shuffles; only the data loads remain in the loop.
+        // EXACT == false: acc = fma(g, w, acc) and nothing else.  The reference's extra 0 * g of an aliased
+        // tap (flag in the weight's sign) changes nothing unless g is not finite -- and then acc is not
+        // finite either (every weight is positive): the wave notices at the end of the walk and walks the
+        // list again the exact way.  (Round 2: the kernel issues 11.4 M VALU instructions at cfg3, 445 per
+        // pixel, half of its time on every SIMD -- the flag's branch and its 8 operations per entry were a
+        // third of them; profiles/r02_pmc_bwd_kernels.md.)
         const unsigned group_base = (threadIdx.x & 63u) & ~(sub - 1u);
-        for (unsigned base = beg; base < end; base += sub) {
-            const unsigned m = min(sub, end - base);
-            const uint2 rec = sl < m ? pairs[base + sl] : make_uint2(0u, 0u);
-            for (unsigned j = 0; j < m; j += kDepth) {
-                v4f g[kDepth];
-                unsigned wb[kDepth];
+        auto walk = [&](auto exact_tag) {
+            constexpr bool EXACT = decltype(exact_tag)::value;
+            v4f acc = z4;
+            for (unsigned base = beg; base < end; base += sub) {
+                const unsigned m = min(sub, end - base);
+                const uint2 rec = sl < m ? pairs[base + sl] : make_uint2(0u, 0u);
+                for (unsigned j = 0; j < m; j += kDepth) {
+                    v4f g[kDepth];
+                    unsigned wb[kDepth];
 #pragma unroll
-                for (int d = 0; d < kDepth; ++d) {
-                    const int from = (int)(group_base + j + d);
-                    const unsigned line = (unsigned)__shfl((int)rec.x, from, kWave);
-                    wb[d] = (unsigned)__shfl((int)rec.y, from, kWave);
-                    g[d] = (c_ok && j + d < m) ? *reinterpret_cast<const v4f*>(src + (size_t)line * line_stride) : z4;
-                }
+                    for (int d = 0; d < kDepth; ++d) {
+                        const int from = (int)(group_base + j + d);
+                        const unsigned line = (unsigned)__shfl((int)rec.x, from, kWave);
+                        wb[d] = (unsigned)__shfl((int)rec.y, from, kWave);
+                        g[d] = (c_ok && j + d < m) ? *reinterpret_cast<const v4f*>(src + (size_t)line * line_stride) : z4;
+                    }
 #pragma unroll
-                for (int d = 0; d < kDepth; ++d) {
-                    if (j + d < m) {
-                        // kernel.cu:260-263: v_k = w_k * top_diff, then one add per tap
-                        acc += g[d] * as_f(wb[d] & 0x7fffffffu);
-                        if (wb[d] & 0x80000000u) acc += g[d] * 0.0f;
+                    for (int d = 0; d < kDepth; ++d) {
+                        if (j + d < m) {
+                            // kernel.cu:260-263: v_k = w_k * top_diff, then one add per tap
+                            const float w = as_f(wb[d] & 0x7fffffffu);
+                            if (EXACT) {
+                                acc += g[d] * w;
+                                if (wb[d] & 0x80000000u) acc += g[d] * 0.0f;
+                            } else {
+                                acc.x = __builtin_fmaf(g[d].x, w, acc.x);
+                                acc.y = __builtin_fmaf(g[d].y, w, acc.y);
+                                acc.z = __builtin_fmaf(g[d].z, w, acc.z);
+                                acc.w = __builtin_fmaf(g[d].w, w, acc.w);
+                            }
+                        }
                     }
                 }
             }
+            return acc;
+        };
+        v4f acc = walk(std::false_type{});
+        {
+            const bool bad = !(fabsf(acc.x) <= 3.0e38f) || !(fabsf(acc.y) <= 3.0e38f) || !(fabsf(acc.z) <= 3.0e38f) ||
+                             !(fabsf(acc.w) <= 3.0e38f);
+            if (__ballot(bad)) acc = walk(std::true_type{});   // rare: a gradient that is not finite
         }
         if (c_ok) {
             // chunk-major gradient (relaid out to NCHW afterwards), or the caller's channels-last
