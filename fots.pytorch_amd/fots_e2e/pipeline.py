@@ -143,13 +143,20 @@ def batched(net, converter, features, boxes, return_crops=False):
     crops_all = _RRoiAlign(TARGET_H, widths[-1], SPATIAL_SCALE)(focr, rois)
     texts = [None] * n
     crops, labels = [None] * n, [None] * n
+    # every bucket's head and decode are enqueued before anything is read back: one wait for the image,
+    # not two per bucket (the buckets' index lists come from the widths that are on the host already)
+    pending = []
+    gw_list = gw_host.tolist()
     for wdt in widths:                                  # buckets are multiples of 32: a handful
-        idx = torch.nonzero(gw_host == wdt).view(-1)
-        x = crops_all[idx.to(focr.device), :, :, :wdt]
+        idx = [i for i, v in enumerate(gw_list) if int(v) == wdt]
+        idx_dev = torch.tensor(idx, dtype=torch.int64).to(focr.device, non_blocking=True)
+        x = crops_all.index_select(0, idx_dev)[:, :, :, :wdt]
         logp = net.forward_ocr(x)
         decoded, dlen, lab = ctc_greedy_decode(logp, None, return_labels=True)
-        decoded, dlen = decoded.cpu(), dlen.cpu()
-        for j, i in enumerate(idx.tolist()):
+        pending.append((idx, decoded, dlen, x, lab))
+    for idx, decoded, dlen, x, lab in pending:
+        decoded, dlen = decoded.cpu(), dlen.cpu()       # the first of these waits for the whole image
+        for j, i in enumerate(idx):
             texts[i] = converter.to_text(decoded[j, :int(dlen[j])])
             if return_crops:
                 crops[i], labels[i] = x[j:j + 1], lab[j].to(torch.int64)
