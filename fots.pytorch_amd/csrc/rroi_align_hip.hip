@@ -32,7 +32,6 @@
 
 #include <algorithm>
 #include <atomic>
-#include <type_traits>
 #include <vector>
 
 #include "rroi_align_hip.h"
@@ -43,7 +42,6 @@ namespace {
 
 #include "rroi_device_common.h"
 #include "rroi_forward_kernels.h"
-#include "rroi_forward_staged_kernels.h"
 #include "rroi_backward_kernels.h"
 #include "rroi_backward_tile_kernels.h"
 #include "rroi_callers_kernels.h"
@@ -257,43 +255,11 @@ bool pick_tiled_fwd(int batch_size, int channels, int height, int width, int num
     const double map_elems = (double)batch_size * channels * height * width;
     return out_elems >= 3.0e6 && out_elems >= map_elems / 4;
 }
-// staged (one launch, NCHW in place) against direct: to be revisited with tools/crossover.py
-bool pick_staged_fwd(int channels, int num_rois, int NB)
-{
-    return (double)num_rois * channels * NB >= 0.5e6;
-}
 bool pick_tiled_bwd(int batch_size, int channels, int height, int width, int num_rois, int NB)
 {
     const double out_elems = (double)num_rois * channels * NB;
     const double map_elems = (double)batch_size * channels * height * width;
     return out_elems >= 0.5e6 && out_elems >= map_elems / 16;
-}
-
-// the staged forward keeps tap coordinates in 15 bits and byte offsets of a chunk's planes in 31
-bool staged_ok(int height, int width, int channels, int pooled_height, int pooled_width)
-{
-    if (height >= 32768 || width >= 32768) return false;
-    if ((long)height * width * 4 * kChunk >= (1L << 31)) return false;
-    if ((long)pooled_height * pooled_width * 4 * kChunk >= (1L << 31)) return false;
-    (void)channels;
-    return true;
-}
-
-// grid of the staged forward: three-wave workgroups, as many as are resident at once (LDS: 25.7 KB each)
-int g_staged_wgs_per_cu = 5;
-int g_staged_aux = 2;  // store policy: 2 = streaming (nt)
-
-int staged_grid(long items, int nchunks)
-{
-    long want = items * nchunks;
-    const long cap = (long)num_cus() * g_staged_wgs_per_cu;
-    if (want > cap) want = cap;
-    long unit = nchunks;
-    while (unit % 8) unit += nchunks;  // lcm(nchunks, 8): blockIdx % nchunks is stable per XCD
-    long g = want / unit * unit;
-    if (g < unit) g = (want + nchunks - 1) / nchunks * nchunks;
-    if (g < nchunks) g = nchunks;
-    return (int)g;
 }
 
 int g_store_aux = 2;   // cache policy of the output stores (see buf_store); 16 / 0 for exploration
@@ -389,35 +355,10 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     if (!shape_ok(batch_size, num_rois, height, width, channels, pooled_height, pooled_width))
         return 0;
     if (feature_layout != RROI_LAYOUT_NCHW && feature_layout != RROI_LAYOUT_NHWC) return 0;
-    if (path != RROI_PATH_AUTO && path != RROI_PATH_DIRECT && path != RROI_PATH_TILED && path != RROI_PATH_STAGED)
-        return 0;
+    if (path != RROI_PATH_AUTO && path != RROI_PATH_DIRECT && path != RROI_PATH_TILED) return 0;
     if (num_rois == 0) return 1;
     if (!features || !rois || !top_data) return 0;
     const int NB = pooled_height * pooled_width;
-
-    // the staged path: NCHW in, NCHW out, one launch, no workspace
-    const bool staged_fits = feature_layout == RROI_LAYOUT_NCHW && !out_nhwc &&
-                             staged_ok(height, width, channels, pooled_height, pooled_width);
-    if (path == RROI_PATH_STAGED && !staged_fits) return 0;
-    if (path == RROI_PATH_STAGED ||
-        (path == RROI_PATH_AUTO && staged_fits && pick_staged_fwd(channels, num_rois, NB))) {
-        if (!(stages & RROI_STAGE_GATHER)) return 1;  // no prologue
-        const int nchunks = ceil_div(channels, kChunk);
-        const int nblk = ceil_div(NB, kStSlots * kWave);
-        if ((long)num_rois * nblk >= (1L << 31)) return 0;
-        const int grid = staged_grid((long)num_rois * nblk, nchunks);
-#define RROI_LAUNCH_ST(AUX)                                                                              \
-    hipLaunchKernelGGL(rroi_fwd_staged_kernel<AUX>, dim3(grid), dim3(3 * kWave), 0, stream, features, rois, \
-                       top_data, num_rois, channels, height, width, pooled_height, pooled_width, NB,         \
-                       spatial_scale, batch_size, nchunks, nblk, make_fastdiv((unsigned)nblk),               \
-                       make_fastdiv((unsigned)pooled_width), g_fwd_dbg)
-        if (g_staged_aux == 0) RROI_LAUNCH_ST(0);
-        else if (g_staged_aux == 16) RROI_LAUNCH_ST(16);
-        else if (g_staged_aux == 17) RROI_LAUNCH_ST(17);
-        else RROI_LAUNCH_ST(2);
-#undef RROI_LAUNCH_ST
-        return launch_status();
-    }
 
     bool tiled;
     if (out_nhwc)
@@ -546,12 +487,6 @@ int rroi_align_debug_set_bwd_relayout_aux(int v)
     const int old = g_bwd_relayout_aux;
     g_bwd_relayout_aux = v;
     return old;
-}
-int rroi_align_debug_set_staged(int wgs_per_cu, int aux)
-{
-    if (wgs_per_cu > 0) g_staged_wgs_per_cu = wgs_per_cu;
-    if (aux >= 0) g_staged_aux = aux;
-    return 1;
 }
 int rroi_align_debug_set_fwd_dbg(int v)
 {

@@ -76,11 +76,6 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
                                     inside the kernel (what TILED runs for C <= 64, and for C <= 128
                                     while there are at most 8 bins per map pixel)            */
 
-#define RROI_PATH_STAGED 6 /* forward only: ONE launch over the NCHW tensor as it is -- no relayout, no
-                              workspace: per (roi, 32-channel chunk) the taps' rows are staged through LDS
-                              by a loader wave and sampled by its partner wave (round 3; what AUTO runs
-                              for NCHW features and NCHW crops)                                        */
-
 /* Bytes of scratch the tiled path needs for this problem (0 for the direct
  * path).  The caller owns the scratch; its contents are dead after the call. */
 size_t rroi_align_forward_workspace_bytes(int batch_size, int channels, int height, int width,

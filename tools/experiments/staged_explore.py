@@ -40,6 +40,11 @@ def main():
     f, r = Wk.bench_inputs(**{k: int(v) for k, v in kw.items() if k in ("R", "C", "H", "W", "img", "seed")})
     if "angle" in kw:
         r[:, 5] = float(kw["angle"])
+    if "hmax" in kw:   # smaller boxes: h ~ U[16, hmax)
+        rng = np.random.default_rng(1)
+        ratio = r[:, 4] / r[:, 3]
+        r[:, 3] = rng.uniform(16, float(kw["hmax"]), len(r)).astype(np.float32)
+        r[:, 4] = r[:, 3] * ratio
     F, R = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
     n, C, H, W = R.shape[0], F.shape[1], F.shape[2], F.shape[3]
     top = torch.empty((n, C, 8, 64), device="cuda")
@@ -52,12 +57,19 @@ def main():
                                         ws.data_ptr(), nbytes, path, stream)
         assert st == 1, st
     res = {}
+    if "short" in sys.argv:
+        res["tiled"] = timeit(lambda: call(PATH_TILED))
+        for dbg in (0, 1, 2, 4):
+            lib.rroi_align_debug_set_fwd_dbg(dbg)
+            res[f"staged_dbg{dbg}"] = timeit(lambda: call(PATH_STAGED))
+        print(json.dumps(res))
+        return
     res["tiled"] = timeit(lambda: call(PATH_TILED))
     res["staged"] = timeit(lambda: call(PATH_STAGED))
-    for wgs in (2, 3, 4, 5, 6):
+    for wgs in (4, 6, 7, 8, 9, 10):
         lib.rroi_align_debug_set_staged(wgs, -1)
         res[f"staged_wgs{wgs}"] = timeit(lambda: call(PATH_STAGED))
-    lib.rroi_align_debug_set_staged(5, -1)
+    lib.rroi_align_debug_set_staged(8, -1)
     for aux in (0, 16, 17, 2):
         lib.rroi_align_debug_set_staged(-1, aux)
         res[f"staged_aux{aux}"] = timeit(lambda: call(PATH_STAGED))
