@@ -15,7 +15,7 @@ environment) or, when those are absent, spawns its N ranks itself.
 Prints ONE JSON line on rank 0.
   value            ROIs/s of the whole job: K steps after W warm-up steps, wall clock between
                    barrier + synchronize on both sides, max over ranks.
-  roofline         the dominant kernel (rroi_fwd_tiled_kernel): algorithmic bytes of one launch /
+  roofline         the dominant kernel (rroi_fwd_split_kernel): algorithmic bytes of one launch /
                    its average duration over a FIXED loop of its own (300 warm-up + 500 timed
                    back-to-back launches between two HIP events on the launch stream -- independent
                    of --steps/--warmup; runs BEFORE the timed steps, so those start on warm clocks).
@@ -24,8 +24,11 @@ Prints ONE JSON line on rank 0.
                    no runnable CPU path) timed on this host's cores -- a reported baseline, not the
                    thing measured.
   extra            N > 1: the step followed by the RCCL all_gather of the crops into one
-                   preallocated (512*N, 256, 8, 64) buffer (`with_gather_ms`), reported beside the
-                   kernel-only step as SURVEY 8(e) asks.
+                   preallocated (512*N, 256, 8, 64) buffer (`with_gather_ms`) and the 25 MiB all_reduce
+                   of the feature gradient (`with_allreduce_grad_ms`), reported beside the kernel-only
+                   step as SURVEY 8(e) asks; `ranks`: what every rank ran on (device UUID, architecture)
+                   and its own ms_per_step -- two ranks on one device fail the run (outside the
+                   one-device self-test).
 """
 import argparse
 import json
@@ -213,6 +216,7 @@ def run(args):
         launch(ext.STAGE_ALL)
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -243,6 +247,37 @@ def run(args):
             del full
         except Exception as e:  # a backend that cannot gather device tensors (self-test over gloo)
             gather_err = repr(e)[:200]
+
+    # ---- N > 1: the feature gradient's all_reduce (25 MiB) and what every rank ran on -----
+    with_allreduce_ms = allreduce_err = ranks_info = None
+    if world > 1:
+        try:
+            grad = torch.zeros((1, c["C"], c["H"], c["W"]), dtype=torch.float32, device="cpu" if one_device else dev)
+            for _ in range(3):
+                dist.all_reduce(grad)
+            barrier()
+            t0 = time.perf_counter()
+            n_a = max(1, min(args.steps, 20))
+            for _ in range(n_a):
+                launch(ext.STAGE_ALL)
+                dist.all_reduce(grad)
+            barrier()
+            ta = torch.tensor([(time.perf_counter() - t0) / n_a * 1e3], dtype=torch.float64,
+                              device="cpu" if one_device else dev)
+            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+            with_allreduce_ms = float(ta.item())
+            del grad
+        except Exception as e:
+            allreduce_err = repr(e)[:200]
+        prop = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local, "device": torch.cuda.current_device(),
+                "uuid": str(getattr(prop, "uuid", "")), "arch": getattr(prop, "gcnArchName", ""),
+                "name": prop.name, "ms_per_step": round(elapsed_local / args.steps * 1e3, 5)}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
+        uuids = [r["uuid"] for r in ranks_info]
+        if not one_device and len(set(uuids)) != world:
+            raise SystemExit("bench.py: %d ranks but the devices are %s -- two ranks share a GPU" % (world, uuids))
 
     # calibration of the bound on this box: a plain device fill of the same 256 MiB output buffer
     fill_ms = event_loop(lambda: out.fill_(0.0), 10, 40)
@@ -330,7 +365,7 @@ def run(args):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes/launch, if collected
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("rroi_fwd_tiled_kernel_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("gather_kernel_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -343,12 +378,15 @@ def run(args):
                                + ": features 1x256x160x160 fp32 NCHW%s, %d rotated ROIs/GPU, "
                                "pooled 8x64, spatial_scale 0.25, forward" % (" replicated" if world > 1 else "", R),
                    "rois_per_gpu": R, "rois_total": R * world, "channels": c["C"],
-                   "pooled": [c["PH"], c["PW"]], "path": "prologue(relayout+affine) + tiled gather",
+                   "pooled": [c["PH"], c["PW"]], "path": "prologue(relayout+affine) + tiled gather (gatherer + storer waves)",
                    "parallelism": "roi-shard x%d, no data-path collective" % world},
-        "roofline": {"bound": "hbm", "kernel": "rroi_fwd_tiled_kernel", "achieved": round(achieved, 1),
+        "roofline": {"bound": "hbm", "kernel": "rroi_fwd_split_kernel", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "whole_call_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "algorithmic_bytes": b_alg,
+                     "traffic": traffic,
+                     "traffic_source": "profiles/traffic.json: FETCH_SIZE (doubled) + WRITE_SIZE of separate rocprofv3 "
+                                       "--pmc passes over this kernel, cold caches -- collected once per round, not in this run",
+                     "algorithmic_bytes": b_alg,
                      "kernel_ms": {"avg": round(gather_ms, 5),
                                    "how": "%d back-to-back launches between two HIP events after %d warm-up "
                                           "launches (includes the ~1 us launch-to-launch gap the rocprofv3 "
@@ -358,7 +396,11 @@ def run(args):
                                     "GB/s": round(fill_gbs, 1), "frac_of_it": round(achieved / fill_gbs, 4)}},
         "cpu_baseline": cpu,
         "extra": {
+            "ranks": ranks_info,
             "with_gather_ms": None if with_gather_ms is None else round(with_gather_ms, 4),
+            "with_allreduce_grad_ms": None if with_allreduce_ms is None else round(with_allreduce_ms, 4),
+            "with_allreduce_grad": None if world == 1 else (
+                allreduce_err or "step + all_reduce of the (1, 256, 160, 160) fp32 feature gradient (25 MiB), max over ranks"),
             "with_gather": None if world == 1 else (
                 gather_err or "step + all_gather_into_tensor of the crops into one preallocated "
                               "(%d, 256, 8, 64) buffer (%.2f GiB), max over ranks" % (R * world, R * world * 524288 / 2 ** 30)),

@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "rroi_align_hip.h"
@@ -108,10 +109,15 @@ bool shape_ok(int batch_size, int num_rois, int height, int width, int channels,
 // multiple of lcm(nchunks, 8) so that blockIdx % nchunks is also stable per XCD.
 int g_waves_per_cu = 12;
 
-int tiled_grid(long items, int nchunks)
+// the split forward kernel: workgroups of a gatherer and a storer wave; 90 VGPRs -> 5 waves per SIMD = 10
+// workgroups per CU (12.1 KB of LDS each); a larger grid would run its surplus as a second round
+int g_split_wgs_per_cu = 10;
+int g_fwd_split = 1;  // 1: loads and stores in different waves (rroi_fwd_split_kernel) for NCHW crops
+
+int tiled_grid(long items, int nchunks, int per_cu = 0)
 {
     long want = items * nchunks;
-    const long cap = (long)num_cus() * g_waves_per_cu;
+    const long cap = (long)num_cus() * (per_cu > 0 ? per_cu : g_waves_per_cu);
     if (want > cap) want = cap;
     long unit = nchunks;
     while (unit % 8) unit += nchunks;  // lcm(nchunks, 8)
@@ -276,6 +282,83 @@ int g_prologue_aux = 0;
 // launches in the call, had nt ahead by 2 us.)  Non-temporal LOADS in the gather: +16 us.
 int g_bwd_relayout_aux = 16;
 
+
+// ------------------------------------------------------------------------------------
+// Scratch of the reference-ABI launchers.  Their signatures carry no workspace, so the library keeps
+// one buffer per (device, stream), grown on demand and reused: calls on one stream are ordered, so the
+// next call may overwrite what the previous one left.  No allocator round trip per call, and a call
+// whose buffer exists enqueues kernels only -- it can be captured into a HIP graph.  (A call made WHILE
+// its stream is capturing and whose buffer would have to grow takes stream-ordered memory for that
+// call alone: the graph owns it.)  rroi_align_release_launcher_scratch() frees everything.
+// ------------------------------------------------------------------------------------
+struct LauncherArena {
+    int device;
+    hipStream_t stream;
+    void* ptr;
+    size_t bytes;
+    unsigned long long last_use;
+};
+constexpr int kMaxArenas = 16;
+std::mutex g_arena_mutex;
+LauncherArena g_arenas[kMaxArenas];
+int g_num_arenas = 0;
+unsigned long long g_arena_clock = 0;
+
+// -> buffer of at least `bytes` for launches on `stream`, or nullptr with *err set.  *transient: the
+// buffer belongs to this call alone (stream capture) and must be given back with hipFreeAsync.
+void* launcher_scratch(hipStream_t stream, size_t bytes, bool* transient, hipError_t* err)
+{
+    *transient = false;
+    *err = hipSuccess;
+    int dev = 0;
+    if ((*err = hipGetDevice(&dev)) != hipSuccess) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    LauncherArena* a = nullptr;
+    for (int i = 0; i < g_num_arenas; ++i)
+        if (g_arenas[i].device == dev && g_arenas[i].stream == stream) a = &g_arenas[i];
+    if (a && a->bytes >= bytes) {
+        a->last_use = ++g_arena_clock;
+        return a->ptr;
+    }
+    if (capturing) {  // do not cache memory that the graph will own
+        void* p = nullptr;
+        *err = hipMallocAsync(&p, bytes, stream);
+        *transient = *err == hipSuccess;
+        return *err == hipSuccess ? p : nullptr;
+    }
+    if (!a) {
+        if (g_num_arenas == kMaxArenas) {
+            // evict the least recently used buffer (its stream may be gone: a synchronous free)
+            int lru = 0;
+            for (int i = 1; i < g_num_arenas; ++i)
+                if (g_arenas[i].last_use < g_arenas[lru].last_use) lru = i;
+            int cur = dev;
+            (void)hipSetDevice(g_arenas[lru].device);
+            (void)hipFree(g_arenas[lru].ptr);
+            (void)hipSetDevice(cur);
+            g_arenas[lru] = g_arenas[--g_num_arenas];
+        }
+        a = &g_arenas[g_num_arenas++];
+        *a = LauncherArena{dev, stream, nullptr, 0, 0};
+    } else {
+        // grow: the old buffer goes back in stream order, behind the launches that still use it
+        if ((*err = hipFreeAsync(a->ptr, stream)) != hipSuccess) return nullptr;
+        a->ptr = nullptr;
+        a->bytes = 0;
+    }
+    void* p = nullptr;
+    if ((*err = hipMallocAsync(&p, bytes, stream)) != hipSuccess) {
+        if (a->ptr == nullptr) *a = g_arenas[--g_num_arenas];  // drop the empty entry
+        return nullptr;
+    }
+    a->ptr = p;
+    a->bytes = bytes;
+    a->last_use = ++g_arena_clock;
+    return p;
+}
+
 }  // namespace
 
 // ====================================================================================
@@ -439,10 +522,29 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     hipLaunchKernelGGL((rroi_fwd_tiled_kernel<VEC, AUX>), dim3(grid), dim3(kWave), 0, stream, map,   \
                        ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,        \
                        batch_size, nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
+        const int sgrid = tiled_grid((long)num_rois * ntiles, nchunks, g_split_wgs_per_cu);
+#define RROI_LAUNCH_SPLIT(VEC)                                                                           \
+    hipLaunchKernelGGL((rroi_fwd_split_kernel<VEC, 2>), dim3(sgrid), dim3(2 * kWave), 0, stream, map,     \
+                       ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size, \
+                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
         if (out_nhwc)
             hipLaunchKernelGGL((rroi_fwd_tiled_kernel<true, 2, true>), dim3(grid), dim3(kWave), 0, stream, map,
                                ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,
                                batch_size, nchunks, ntiles, lay, dt, dp, g_fwd_dbg);
+#ifdef RROI_EXPLORE
+#define RROI_LAUNCH_SPLIT_X(M)                                                                               \
+    hipLaunchKernelGGL((rroi_fwd_split_kernel<true, 2, 2, M>), dim3(sgrid), dim3(2 * kWave), 0, stream, map,   \
+                       ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,     \
+                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
+        else if (g_fwd_split == 2) RROI_LAUNCH_SPLIT_X(0);
+        else if (g_fwd_split == 3) RROI_LAUNCH_SPLIT_X(2);
+        else if (g_fwd_split == 4) RROI_LAUNCH_SPLIT_X(3);
+        else if (g_fwd_split == 5) RROI_LAUNCH_SPLIT_X(4);
+        else if (g_fwd_split == 6) RROI_LAUNCH_SPLIT_X(8);
+#undef RROI_LAUNCH_SPLIT_X
+#endif
+        else if (g_fwd_split && g_store_aux == 2 && NB % 4 != 0) RROI_LAUNCH_SPLIT(false);
+        else if (g_fwd_split && g_store_aux == 2) RROI_LAUNCH_SPLIT(true);
         else if (NB % 4 != 0) RROI_LAUNCH_FWD(false, 2);
         else if (g_store_aux == 0) RROI_LAUNCH_FWD(true, 0);    // exploration only
         else if (g_store_aux == 16) RROI_LAUNCH_FWD(true, 16);  // exploration only
@@ -468,6 +570,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
 #endif
         else RROI_LAUNCH_FWD(true, 2);
 #undef RROI_LAUNCH_FWD
+#undef RROI_LAUNCH_SPLIT
     }
     return launch_status();
 }
@@ -486,6 +589,13 @@ int rroi_align_debug_set_bwd_relayout_aux(int v)
 {
     const int old = g_bwd_relayout_aux;
     g_bwd_relayout_aux = v;
+    return old;
+}
+int rroi_align_debug_set_fwd_split(int on, int wgs_per_cu)
+{
+    const int old = g_fwd_split;
+    if (on >= 0) g_fwd_split = on;
+    if (wgs_per_cu > 0) g_split_wgs_per_cu = wgs_per_cu;
     return old;
 }
 int rroi_align_debug_set_fwd_dbg(int v)
@@ -544,11 +654,27 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
                                           stream_);
 }
 
+static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_diff_layout,
+                         float spatial_scale, int batch_size, int num_rois, int height, int width, int channels,
+                         int pooled_height, int pooled_width, const float* rois, float* bottom_diff,
+                         void* workspace, size_t workspace_bytes, int path, void* stream_, bool accumulate);
+
 int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, int bottom_diff_layout,
                                    float spatial_scale, int batch_size, int num_rois, int height,
                                    int width, int channels, int pooled_height, int pooled_width,
                                    const float* rois, float* bottom_diff, void* workspace,
                                    size_t workspace_bytes, int path, void* stream_)
+{
+    return backward_impl(top_diff, top_diff_layout, bottom_diff_layout, spatial_scale, batch_size, num_rois, height,
+                         width, channels, pooled_height, pooled_width, rois, bottom_diff, workspace, workspace_bytes,
+                         path, stream_, false);
+}
+
+// accumulate (the reference-ABI launcher, tiled NCHW paths only): bottom_diff += gradient instead of = gradient
+static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_diff_layout,
+                         float spatial_scale, int batch_size, int num_rois, int height, int width, int channels,
+                         int pooled_height, int pooled_width, const float* rois, float* bottom_diff,
+                         void* workspace, size_t workspace_bytes, int path, void* stream_, bool accumulate)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (top_diff_layout != RROI_LAYOUT_NCHW && top_diff_layout != RROI_LAYOUT_NHWC) return 0;
@@ -573,6 +699,7 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
     const bool tiled = td_nhwc || bd_nhwc || (path == RROI_PATH_AUTO
                                        ? pick_tiled_bwd(batch_size, channels, height, width, num_rois, NB)
                                        : path != RROI_PATH_DIRECT);
+    if (accumulate && (!tiled || bd_nhwc)) return 0;
     if (!tiled) {
         hipError_t e = hipMemsetAsync(bottom_diff, 0, in_bytes, stream);
         if (e != hipSuccess) return status_of(e);
@@ -768,9 +895,14 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
         st = launch_status();
         if (st != 1) return st;
     }
-    hipLaunchKernelGGL(rroi_cm_to_nchw_kernel, dim3(ptiles * nchunks * batch_size), dim3(256), 0,
-                       stream, ws.gcm, bottom_diff, channels, (int)HW, width, pitch,
-                       make_fastdiv((unsigned)width), nchunks, ptiles);
+    if (accumulate)
+        hipLaunchKernelGGL(rroi_cm_to_nchw_kernel<true>, dim3(ptiles * nchunks * batch_size), dim3(256), 0,
+                           stream, ws.gcm, bottom_diff, channels, (int)HW, width, pitch,
+                           make_fastdiv((unsigned)width), nchunks, ptiles);
+    else
+        hipLaunchKernelGGL(rroi_cm_to_nchw_kernel<false>, dim3(ptiles * nchunks * batch_size), dim3(256), 0,
+                           stream, ws.gcm, bottom_diff, channels, (int)HW, width, pitch,
+                           make_fastdiv((unsigned)width), nchunks, ptiles);
     return launch_status();
 }
 
@@ -903,9 +1035,10 @@ int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
     // which trusts the index as the reference does.  When there are none that launch only reads
     // the ROI rows.
     const size_t bytes = carve(nullptr, 1, channels, height, width, num_rois, RROI_LAYOUT_NCHW).bytes;
-    void* ws = nullptr;
-    hipError_t e = hipMallocAsync(&ws, bytes, stream);
-    if (e != hipSuccess) return status_of(e);
+    bool transient;
+    hipError_t e;
+    void* ws = launcher_scratch(stream, bytes, &transient, &e);
+    if (!ws) return status_of(e);
     int st = forward_impl(bottom_data, RROI_LAYOUT_NCHW, RROI_LAYOUT_NCHW, spatial_scale, 1, num_rois, height,
                           width, channels, pooled_height, pooled_width, bottom_rois, top_data, ws, bytes,
                           RROI_PATH_TILED, RROI_STAGE_ALL, stream_);
@@ -920,14 +1053,15 @@ int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
                            num_rois, channels, height, width, pooled_height, pooled_width, spatial_scale, cslab);
         st = launch_status();
     }
-    e = hipFreeAsync(ws, stream);
+    if (transient) e = hipFreeAsync(ws, stream);
     return st != 1 ? st : status_of(e);
 }
 
 // con_idx_x / con_idx_y must be the tensors the forward wrote for the same rois (the reference
 // re-reads the bin centres from them, kernel.cu:232-233): the fast path recomputes the centres from
-// the rois instead of reading 2 x (R, C, PH, PW) floats back.  bottom_diff: zero on entry, as the
-// reference requires (functions/rroi_align.py:35) -- the fast path overwrites, the direct path adds.
+// the rois instead of reading 2 x (R, C, PH, PW) floats back.  bottom_diff: the gradient is ADDED to it
+// on every path, as the reference's atomicAdds do (kernel.cu:260-274; functions/rroi_align.py:35 hands
+// over zeros) -- the result does not depend on which path the problem size selects.
 int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
                              const int batch_size, const int num_rois, const int height,
                              const int width, const int channels, const int pooled_height,
@@ -943,14 +1077,14 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
     const int NB = pooled_height * pooled_width;
     if (pick_tiled_bwd(batch_size, channels, height, width, num_rois, NB)) {
         const size_t bytes = carve_bwd(nullptr, batch_size, channels, height, width, num_rois, NB).bytes;
-        void* ws = nullptr;
-        hipError_t e = hipMallocAsync(&ws, bytes, stream);
-        if (e != hipSuccess) return status_of(e);
-        const int st = rroi_align_backward_layout_hip(top_diff, RROI_LAYOUT_NCHW, RROI_LAYOUT_NCHW, spatial_scale,
-                                                      batch_size, num_rois, height, width, channels, pooled_height,
-                                                      pooled_width, bottom_rois, bottom_diff, ws, bytes,
-                                                      RROI_PATH_TILED, stream_);
-        e = hipFreeAsync(ws, stream);
+        bool transient;
+        hipError_t e;
+        void* ws = launcher_scratch(stream, bytes, &transient, &e);
+        if (!ws) return status_of(e);
+        const int st = backward_impl(top_diff, RROI_LAYOUT_NCHW, RROI_LAYOUT_NCHW, spatial_scale, batch_size, num_rois,
+                                     height, width, channels, pooled_height, pooled_width, bottom_rois, bottom_diff,
+                                     ws, bytes, RROI_PATH_TILED, stream_, /*accumulate*/ true);
+        if (transient) e = hipFreeAsync(ws, stream);
         return st != 1 ? st : status_of(e);
     }
     const long nthreads = (long)num_rois * pooled_height * pooled_width * channels;
@@ -961,6 +1095,22 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
                        top_diff, con_idx_x, con_idx_y, bottom_rois, bottom_diff, nthreads, channels,
                        height, width, pooled_height, pooled_width);
     return launch_status();
+}
+
+int rroi_align_release_launcher_scratch(void)
+{
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < g_num_arenas; ++i) {
+        (void)hipSetDevice(g_arenas[i].device);
+        const hipError_t ei = hipFree(g_arenas[i].ptr);  // synchronous: the buffers' streams may be gone
+        if (ei != hipSuccess) e = ei;
+    }
+    g_num_arenas = 0;
+    (void)hipSetDevice(cur);
+    return status_of(e);
 }
 
 }  // extern "C"

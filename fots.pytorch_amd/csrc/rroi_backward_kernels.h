@@ -446,6 +446,9 @@ __global__ __launch_bounds__(kWave) void rroi_bwd_tiled_kernel(
 }
 
 // chunk-major gradient (B, nchunks, HW, 32) -> NCHW (B, C, HW); inverse of the prologue's tile.
+// ACCUM (the reference-ABI launcher): bottom_diff += the gradient, as the reference's atomicAdds onto its
+// zeroed buffer do (kernel.cu:260-274) -- a caller that accumulates over several calls gets the sum
+template <bool ACCUM = false>
 __global__ __launch_bounds__(256) void rroi_cm_to_nchw_kernel(const float* __restrict__ cm,
                                                               float* __restrict__ nchw, int C,
                                                               int HW, int width, int pitch,
@@ -484,7 +487,11 @@ __global__ __launch_bounds__(256) void rroi_cm_to_nchw_kernel(const float* __res
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
             const int p = hlf * 64 + lane;
-            if (c0 + c < C && p0 + p < HW) dst[(size_t)c * HW + p] = T[c * (kRelayoutPx + 1) + p];
+            if (c0 + c < C && p0 + p < HW) {
+                float* o = dst + (size_t)c * HW + p;
+                const float v = T[c * (kRelayoutPx + 1) + p];
+                *o = ACCUM ? *o + v : v;
+            }
         }
     }
 }

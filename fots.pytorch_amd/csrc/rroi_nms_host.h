@@ -29,25 +29,122 @@ inline double nms_area2(const double* px, const double* py, int n)
     return s;
 }
 
+// A quad is convex (and simple) iff its four corner cross products have one strict sign.
+inline bool nms_quad_convex(const double* x, const double* y)
+{
+    int pos = 0, neg = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int j = (i + 1) % 4, k = (i + 2) % 4;
+        const double c = (x[j] - x[i]) * (y[k] - y[j]) - (y[j] - y[i]) * (x[k] - x[j]);
+        pos += c > 0;
+        neg += c < 0;
+    }
+    return pos == 4 || neg == 4;
+}
+
+// even-odd point-in-quad (ray to +x, half-open in y)
+inline bool nms_inside_evenodd(const double* x, const double* y, double px, double py)
+{
+    bool in = false;
+    for (int i = 0; i < 4; ++i) {
+        const int j = (i + 1) % 4;
+        if ((y[i] > py) != (y[j] > py)) {
+            const double xi = x[i] + (py - y[i]) / (y[j] - y[i]) * (x[j] - x[i]);
+            if (xi > px) in = !in;
+        }
+    }
+    return in;
+}
+
+// Areas of (A and B) and (A or B) for two quads of ANY shape under the even-odd fill rule -- what
+// ClipperLib's Execute(ctIntersection / ctUnion, ..., pftEvenOdd) + Area() give (nms.h:24-36): merged
+// quads are per-coordinate weighted means with different weights for X and Y (nms.h:87-96) and need not
+// stay convex or simple.  Every edge is cut at its crossings with the other quad's edges and with its own
+// quad's non-adjacent edges, the crossing points ROUNDED to integers as Clipper stores them; a piece of A
+// bounds the intersection when it lies inside B (the union: outside B), and symmetrically; each piece is
+// oriented so that its own quad's interior is on its left, and Green's theorem sums the area.
+// (bx == nullptr: one quad alone; `uni` is its even-odd area.)
+inline void nms_evenodd_areas(const double* ax, const double* ay, const double* bx, const double* by,
+                              double& inter, double& uni)
+{
+    const double* X[2] = {ax, bx};
+    const double* Y[2] = {ay, by};
+    const int nq = bx ? 2 : 1;
+    // crossing of edge (q, i) with edge (r, j): parameter on each edge and the shared rounded point
+    struct Cut { double t, px, py; };
+    Cut cuts[2][4][8];
+    int ncut[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int e = 0; e < 4 * nq; ++e)
+        for (int f = e + 1; f < 4 * nq; ++f) {
+            const int q = e / 4, i = e % 4, r = f / 4, j = f % 4;
+            if (q == r && ((i + 1) % 4 == j || (j + 1) % 4 == i)) continue;  // adjacent edges share a vertex
+            const double x1 = X[q][i], y1 = Y[q][i], x2 = X[q][(i + 1) % 4], y2 = Y[q][(i + 1) % 4];
+            const double x3 = X[r][j], y3 = Y[r][j], x4 = X[r][(j + 1) % 4], y4 = Y[r][(j + 1) % 4];
+            const double d = (x2 - x1) * (y4 - y3) - (y2 - y1) * (x4 - x3);
+            if (d == 0) continue;  // parallel
+            const double t = ((x3 - x1) * (y4 - y3) - (y3 - y1) * (x4 - x3)) / d;
+            const double u = ((x3 - x1) * (y2 - y1) - (y3 - y1) * (x2 - x1)) / d;
+            if (!(t > 0 && t < 1 && u > 0 && u < 1)) continue;
+            const double px = floor(x1 + t * (x2 - x1) + 0.5), py = floor(y1 + t * (y2 - y1) + 0.5);
+            cuts[q][i][ncut[q][i]++] = Cut{t, px, py};
+            cuts[r][j][ncut[r][j]++] = Cut{u, px, py};
+        }
+    inter = uni = 0.0;
+    for (int q = 0; q < nq; ++q) {
+        const double *ox = X[1 - q], *oy = Y[1 - q];
+        for (int i = 0; i < 4; ++i) {
+            const double x1 = X[q][i], y1 = Y[q][i], x2 = X[q][(i + 1) % 4], y2 = Y[q][(i + 1) % 4];
+            Cut* c = cuts[q][i];
+            const int n = ncut[q][i];
+            std::sort(c, c + n, [](const Cut& a, const Cut& b) { return a.t < b.t; });
+            const double len = sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1));
+            if (len == 0) continue;
+            const double nx = -(y2 - y1) / len, ny = (x2 - x1) / len;  // left normal
+            double t0 = 0.0, sx = x1, sy = y1;
+            for (int k = 0; k <= n; ++k) {
+                const double t1 = k < n ? c[k].t : 1.0;
+                const double ex = k < n ? c[k].px : x2, ey = k < n ? c[k].py : y2;
+                const double tm = 0.5 * (t0 + t1);
+                const double mx = x1 + tm * (x2 - x1), my = y1 + tm * (y2 - y1);
+                // which side of this piece is its own quad's interior (none: an edge covered twice)
+                const double eps = 1e-3;  // coordinates are integers (1/10000 px)
+                const bool left = nms_inside_evenodd(X[q], Y[q], mx + eps * nx, my + eps * ny);
+                const bool right = nms_inside_evenodd(X[q], Y[q], mx - eps * nx, my - eps * ny);
+                if (left != right) {
+                    const double cr = 0.5 * (sx * ey - ex * sy) * (left ? 1.0 : -1.0);
+                    if (nq == 2 && nms_inside_evenodd(ox, oy, mx, my)) inter += cr;  // bounds A and B
+                    else uni += cr;                                                    // bounds A or B
+                }
+                t0 = t1;
+                sx = ex;
+                sy = ey;
+            }
+        }
+    }
+}
+
 inline float nms_poly_iou(const NmsPoly& a, const NmsPoly& b)
 {
     double ax[4], ay[4], bx[4], by[4];
+    bool same = true;
     for (int i = 0; i < 4; ++i) {
         ax[i] = (double)a.X[i];
         ay[i] = (double)a.Y[i];
         bx[i] = (double)b.X[i];
         by[i] = (double)b.Y[i];
+        same = same && a.X[i] == b.X[i] && a.Y[i] == b.Y[i];
     }
-    const double a2 = nms_area2(ax, ay, 4);
-    double b2 = nms_area2(bx, by, 4);
-    if (b2 < 0) {  // clip polygon counter-clockwise
-        for (int i = 0; i < 2; ++i) {
-            std::swap(bx[i], bx[3 - i]);
-            std::swap(by[i], by[3 - i]);
+    double inter = 0.0, uni = 0.0;
+    if (nms_quad_convex(ax, ay) && nms_quad_convex(bx, by)) {
+        // two convex quads: Sutherland-Hodgman, crossing points rounded to integers as Clipper rounds them
+        const double a2 = nms_area2(ax, ay, 4);
+        double b2 = nms_area2(bx, by, 4);
+        if (b2 < 0) {  // clip polygon counter-clockwise
+            for (int i = 0; i < 2; ++i) {
+                std::swap(bx[i], bx[3 - i]);
+                std::swap(by[i], by[3 - i]);
+            }
         }
-    }
-    double inter = 0.0;
-    if (a2 != 0 && b2 != 0) {
         double ox[16], oy[16], ix[16], iy[16];
         int n = 4;
         for (int i = 0; i < 4; ++i) {
@@ -78,8 +175,15 @@ inline float nms_poly_iou(const NmsPoly& a, const NmsPoly& b)
             }
         }
         inter = fabs(nms_area2(ox, oy, n)) / 2.0;
+        uni = fabs(a2) / 2.0 + fabs(b2) / 2.0 - inter;
+    } else if (same) {
+        // the same (non-convex) quad twice (nms.h:198/201 append a polygon twice): every edge coincides
+        double none;
+        nms_evenodd_areas(ax, ay, nullptr, nullptr, none, uni);
+        inter = uni;
+    } else {
+        nms_evenodd_areas(ax, ay, bx, by, inter, uni);
     }
-    const double uni = fabs(a2) / 2.0 + fabs(b2) / 2.0 - inter;
     const float inter_f = (float)inter, uni_f = (float)uni;  // `float area` of paths_area (nms.h:17-22)
     return fabsf(inter_f) / std::max(fabsf(uni_f), 1.0f);
 }

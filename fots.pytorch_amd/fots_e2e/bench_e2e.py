@@ -93,9 +93,35 @@ def measure(device, reps=5, channels_last=False):
             same = texts if same is None else (same == texts)
     # the detector's post-processing on its own (see the module docstring): 24 words at 1280 x 704
     from rroi_align.nms import get_boxes
-    from .pipeline import synthetic_detector_maps
+    from .pipeline import infer_image, synthetic_detector_maps
     maps = [tuple(torch.from_numpy(a).to(device) for a in synthetic_detector_maps(704, 1280, BOXES_PER_IMAGE, seed=i))
             for i in range(len(ims))]
+    # ---- the whole chain of test.py:75-116 per image: preprocess, net, get_boxes ON the maps (the
+    # synthetic trained-detector maps stand in for the three head outputs), recognition of ITS boxes
+    with torch.no_grad():
+        for name in ("per_box", "batched"):
+            def chain(i, im):
+                return infer_image(net, conv, im, detector=lambda _x, m=maps[i]: m, recognise=name)
+            for i, im in enumerate(ims):
+                chain(i, im)                                   # warm-up
+            per_image, nbox = [], 0
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                for i, im in enumerate(ims):
+                    t1 = time.perf_counter()
+                    b, _t = chain(i, im)
+                    torch.cuda.synchronize(device)
+                    per_image.append(time.perf_counter() - t1)
+                    nbox += len(b)
+            wall = time.perf_counter() - t0
+            out[name]["chain_images_per_s"] = round(1.0 / float(np.median(per_image)), 2)
+            out[name]["chain_images_per_s_mean"] = round(len(per_image) / wall, 2)
+            out[name]["chain_boxes_per_image"] = round(nbox / len(per_image), 1)
+    out["chain"] = ("chain_*: preprocess + net + rroi_align.nms.get_boxes on the device maps (synthetic trained-detector "
+                    "maps injected for the three head outputs: random weights pass no box) + recognition of the boxes "
+                    "get_boxes returned; host synchronisations per image on the batched path: the read-back of the "
+                    "passing pixels before the merge, then the decoded labels")
     times, found = [], 0
     for rep in range(reps + 1):
         for m in maps:

@@ -130,15 +130,23 @@ def per_box(net, converter, features, boxes, return_crops=False):
     return (texts, crops, labels) if return_crops else texts
 
 
-def batched(net, converter, features, boxes, return_crops=False):
-    """All words of an image at once.  `boxes`: (N, >= 8) tensor on the device (or array)."""
+def batched(net, converter, features, boxes, return_crops=False, gw_host=None):
+    """All words of an image at once.  `boxes`: (N, >= 8) tensor on the device (or array).
+    `gw_host`: the boxes' pooled widths when the caller already has them on the host (`infer_image`:
+    the boxes come out of the host-side merge, and the width rule is `host_roi`'s) -- then nothing is
+    read back before the head."""
     focr = features[1]
     quads = torch.as_tensor(boxes, dtype=torch.float32, device=focr.device)[:, :8].contiguous()
     n = quads.shape[0]
     if n == 0:
         return ([], [], []) if return_crops else []
     rois, gw = rois_from_quads(quads, None, False, TARGET_H)
-    gw_host = gw.cpu()                                  # the one read-back before the head
+    if gw_host is None:
+        gw_host = gw.cpu()                              # the one read-back before the head
+    else:
+        gw_host = torch.as_tensor(gw_host, dtype=torch.int32)
+        if gw_host.numel() != n:
+            raise ValueError("gw_host must have one width per box")
     widths = sorted(set(int(v) for v in gw_host))
     crops_all = _RRoiAlign(TARGET_H, widths[-1], SPATIAL_SCALE)(focr, rois)
     texts = [None] * n
@@ -161,3 +169,38 @@ def batched(net, converter, features, boxes, return_crops=False):
             if return_crops:
                 crops[i], labels[i] = x[j:j + 1], lab[j].to(torch.int64)
     return (texts, crops, labels) if return_crops else texts
+
+
+def infer_image(net, converter, im, detector=None, segm_thresh=0.5, recognise="batched", return_debug=False):
+    """One image through the whole chain of `test.py:75-116`: preprocess -> net -> `get_boxes` on the maps
+    where the network wrote them -> RoIRotate + recognition head + greedy CTC for every box ->
+    (boxes (n, 9) numpy, texts); like the reference's loop, boxes whose text is empty are dropped
+    (test.py:109-110).
+
+    `detector`: optional hook `im_data -> (score (h, w), rbox (4, h, w), angle (2, h, w))` device tensors
+    that stand in for the three head outputs -- random weights pass no box (or a hundred thousand)
+    through the NMS, so tests and the benchmark inject `synthetic_detector_maps` here.
+    `recognise`: "batched" (the MI355X shape) or "per_box" (the reference's loop, kept as the checker).
+
+    Host synchronisations per image on the batched path: ONE before the head (`get_boxes` reads the
+    number of passing pixels and their records: the merge is sequential host code) and the final
+    read-back of the decoded labels.  The pooled-width buckets need no second one: the boxes are on
+    the host after the merge and the width rule is plain arithmetic (`host_roi`)."""
+    from rroi_align.nms import get_boxes
+    device = next(net.parameters()).device
+    im_data = preprocess(im, device) if not isinstance(im, torch.Tensor) else im
+    score, rbox, angle, feats = net(im_data)
+    if detector is not None:
+        s, r, a = detector(im_data)
+    else:
+        s, r, a = score[0][0, 0], rbox[0][0], angle[0][0]
+    boxes = get_boxes(s, r, a, segm_thresh)
+    if recognise == "per_box":
+        out = per_box(net, converter, feats, boxes, return_crops=return_debug)
+    else:
+        gw = [host_roi(b)[1] for b in boxes]
+        out = batched(net, converter, feats, boxes, return_crops=return_debug, gw_host=gw)
+    texts = out[0] if return_debug else out
+    keep = [i for i, t in enumerate(texts) if len(t) > 0]
+    res = (boxes[keep], [texts[i] for i in keep])
+    return res + ((boxes, out),) if return_debug else res

@@ -10,8 +10,10 @@ The shared library is mandatory: importing this module without it raises.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -69,6 +71,8 @@ _lib.RROIAlignForwardLaucher.restype = _i
 _lib.RROIAlignForwardLaucher.argtypes = [_vp, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.RROIAlignBackwardLaucher.restype = _i
 _lib.RROIAlignBackwardLaucher.argtypes = [_vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
+_lib.rroi_align_release_launcher_scratch.restype = _i
+_lib.rroi_align_release_launcher_scratch.argtypes = []
 
 EXPORTS = (
     "RROIAlignForwardLaucher", "RROIAlignBackwardLaucher", "rroi_align_forward_hip",
@@ -77,6 +81,7 @@ EXPORTS = (
     "rroi_align_sincos_probe_hip", "rroi_align_quads_to_rois_hip", "rroi_align_hip_version",
     "rroi_ctc_greedy_decode_hip", "rroi_align_backward_layout_hip", "rroi_align_forward_layout_hip",
     "rroi_align_gt_quads_to_rois_hip", "rroi_rbox_decode_hip", "rroi_nms_merge_host",
+    "rroi_align_release_launcher_scratch",
 )
 
 
@@ -98,27 +103,42 @@ def _stream() -> int:
 
 # Scratch for the tiled paths, one buffer per (device, stream), grown on demand and reused: calls on
 # one stream are ordered, so the next call may overwrite what the previous one left (the contents
-# are dead after a call); another stream gets its own buffer.  Saves the allocator round trip and,
-# for the backward at BASELINE configs[2], a 304 MB request per step.
-_scratch = {}
+# are dead after a call); another stream gets its own buffer.  Saves the allocator round trip per call.
+# What is kept is bounded: a request above _SCRATCH_KEEP_BYTES (the backward of a 4096-ROI problem asks
+# for 2.4 GB) is served by a plain allocation that goes back to torch's caching allocator with the call,
+# at most _SCRATCH_MAX_STREAMS buffers are kept (least recently used first out; a buffer whose stream
+# has been destroyed ages out this way), and the table is guarded by a lock.
+_SCRATCH_KEEP_BYTES = 512 << 20
+_SCRATCH_MAX_STREAMS = 8
+_scratch = collections.OrderedDict()
+_scratch_lock = threading.Lock()
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    if torch.cuda.is_current_stream_capturing():  # a graph owns its memory: nothing of it is cached
+    if nbytes > _SCRATCH_KEEP_BYTES or torch.cuda.is_current_stream_capturing():
+        # too large to pin, or a graph owns its memory: nothing of it is cached
         return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _scratch.get(key)
-    if buf is None or buf.numel() < nbytes:
+    with _scratch_lock:
+        buf = _scratch.get(key)
+        if buf is not None and buf.numel() >= nbytes:
+            _scratch.move_to_end(key)
+            return buf
         buf = None
         _scratch.pop(key, None)           # release the smaller buffer before asking for the larger one
+        while len(_scratch) >= _SCRATCH_MAX_STREAMS:
+            _scratch.popitem(last=False)
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         _scratch[key] = buf
-    return buf
+        return buf
 
 
 def release_workspaces() -> None:
-    """Drop the cached scratch buffers (they are re-created on demand)."""
-    _scratch.clear()
+    """Drop the cached scratch buffers -- the Python surface's and the library's own (the per-stream
+    scratch of the reference-ABI launchers); all of them are re-created on demand."""
+    with _scratch_lock:
+        _scratch.clear()
+    _check(_lib.rroi_align_release_launcher_scratch(), "rroi_align_release_launcher_scratch")
 
 
 def _require_cuda_f32(t: torch.Tensor, name: str) -> None:

@@ -41,8 +41,9 @@ int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
                             const float* bottom_rois, float* top_data, float* con_idx_x,
                             float* con_idx_y, void* stream);
 
-/*  top_diff : (R, C, PH, PW) fp32;  bottom_diff : (B, C, H, W) fp32, must be
- *  zero on entry exactly as in the reference (functions/rroi_align.py:35);
+/*  top_diff : (R, C, PH, PW) fp32;  bottom_diff : (B, C, H, W) fp32: the gradient is
+ *  ADDED to it, whatever the problem size, as the reference's atomicAdds do -- zero it
+ *  first for the plain gradient (functions/rroi_align.py:35 does);
  *  con_idx_x/y : the tensors the forward wrote (read per element, as
  *  kernel.cu:232-233 does). */
 int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
@@ -51,6 +52,12 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
                              const int pooled_width, const float* bottom_rois,
                              float* bottom_diff, const float* con_idx_x, const float* con_idx_y,
                              void* stream);
+
+/* The two launchers above carry no workspace argument: the library keeps one scratch buffer per
+ * (device, stream), grown on demand and reused by later calls on that stream (no allocation per call;
+ * a call whose buffer exists only enqueues kernels and can be captured into a HIP graph).  This frees
+ * all of them (synchronously); they are re-created on demand.  Returns 1 / -hipError. */
+int rroi_align_release_launcher_scratch(void);
 
 /* ------------------------------------------------------------------------- *
  * 2. The MI355X-native entry points used by the Python surface

@@ -119,14 +119,93 @@ def _clip(subject, clip):
     return out
 
 
+def _convex(p):
+    """all four corner cross products of one strict sign: a convex, simple quad"""
+    pos = neg = 0
+    for i in range(4):
+        (x0, y0), (x1, y1), (x2, y2) = p[i], p[(i + 1) % 4], p[(i + 2) % 4]
+        c = (float(x1) - float(x0)) * (float(y2) - float(y1)) - (float(y1) - float(y0)) * (float(x2) - float(x1))
+        pos += c > 0
+        neg += c < 0
+    return pos == 4 or neg == 4
+
+
+def _inside_evenodd(p, px, py):
+    inside = False
+    for i in range(4):
+        (xi, yi), (xj, yj) = p[i], p[(i + 1) % 4]
+        xi, yi, xj, yj = float(xi), float(yi), float(xj), float(yj)
+        if (yi > py) != (yj > py):
+            if xi + (py - yi) / (yj - yi) * (xj - xi) > px:
+                inside = not inside
+    return inside
+
+
+def _evenodd_areas(pa, pb):
+    """(area of A and B, area of A or B) under the even-odd fill rule for quads of any shape -- what
+    Clipper's Execute(ctIntersection / ctUnion, pftEvenOdd) + Area() return (nms.h:24-36).  Edges are
+    cut at their crossings (points rounded to integers, as Clipper stores them); a piece of A bounds
+    the intersection when it lies inside B, else the union, and symmetrically; Green's theorem with
+    every piece oriented so that its own quad's interior is on its left.  pb = None: A alone."""
+    polys = [pa] if pb is None else [pa, pb]
+    edges = [(q, i) for q in range(len(polys)) for i in range(4)]
+    cuts = {e: [] for e in edges}
+    for ei, (q, i) in enumerate(edges):
+        for (r, j) in edges[ei + 1:]:
+            if q == r and ((i + 1) % 4 == j or (j + 1) % 4 == i):
+                continue
+            (x1, y1), (x2, y2) = polys[q][i], polys[q][(i + 1) % 4]
+            (x3, y3), (x4, y4) = polys[r][j], polys[r][(j + 1) % 4]
+            x1, y1, x2, y2, x3, y3, x4, y4 = (float(v) for v in (x1, y1, x2, y2, x3, y3, x4, y4))
+            d = (x2 - x1) * (y4 - y3) - (y2 - y1) * (x4 - x3)
+            if d == 0:
+                continue
+            t = ((x3 - x1) * (y4 - y3) - (y3 - y1) * (x4 - x3)) / d
+            u = ((x3 - x1) * (y2 - y1) - (y3 - y1) * (x2 - x1)) / d
+            if not (0 < t < 1 and 0 < u < 1):
+                continue
+            pt = (float(math.floor(x1 + t * (x2 - x1) + 0.5)), float(math.floor(y1 + t * (y2 - y1) + 0.5)))
+            cuts[(q, i)].append((t, pt))
+            cuts[(r, j)].append((u, pt))
+    inter = uni = 0.0
+    for (q, i) in edges:
+        (x1, y1), (x2, y2) = polys[q][i], polys[q][(i + 1) % 4]
+        x1, y1, x2, y2 = float(x1), float(y1), float(x2), float(y2)
+        ln = math.sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1))
+        if ln == 0:
+            continue
+        nx, ny = -(y2 - y1) / ln, (x2 - x1) / ln
+        t0, (sx, sy) = 0.0, (x1, y1)
+        for t1, (ex, ey) in sorted(cuts[(q, i)], key=lambda c: c[0]) + [(1.0, (x2, y2))]:
+            tm = 0.5 * (t0 + t1)
+            mx, my = x1 + tm * (x2 - x1), y1 + tm * (y2 - y1)
+            left = _inside_evenodd(polys[q], mx + 1e-3 * nx, my + 1e-3 * ny)
+            right = _inside_evenodd(polys[q], mx - 1e-3 * nx, my - 1e-3 * ny)
+            if left != right:
+                cr = 0.5 * (sx * ey - ex * sy) * (1.0 if left else -1.0)
+                if pb is not None and _inside_evenodd(polys[1 - q], mx, my):
+                    inter += cr
+                else:
+                    uni += cr
+            t0, (sx, sy) = t1, (ex, ey)
+    return inter, uni
+
+
 def poly_iou(a, b):
-    """nms.h:24-36."""
+    """nms.h:24-36.  Two convex quads: Sutherland-Hodgman (crossing points rounded as Clipper rounds them);
+    a quad that is not convex or not simple -- merged quads are per-coordinate weighted means with
+    different weights for X and Y, nms.h:87-96 -- takes the even-odd arrangement."""
     pa, pb = a["poly"], b["poly"]
-    a2, b2 = _area2(pa), _area2(pb)
-    clip = pb if b2 >= 0 else pb[::-1]
-    inter = abs(_area2(_clip(pa, clip))) / 2.0 if a2 != 0 and b2 != 0 else 0.0
-    area_a, area_b = abs(a2) / 2.0, abs(b2) / 2.0
-    uni = area_a + area_b - inter
+    if _convex(pa) and _convex(pb):
+        a2, b2 = _area2(pa), _area2(pb)
+        clip = pb if b2 >= 0 else pb[::-1]
+        inter = abs(_area2(_clip(pa, clip))) / 2.0
+        uni = abs(a2) / 2.0 + abs(b2) / 2.0 - inter
+    elif all(tuple(u) == tuple(v) for u, v in zip(pa, pb)):
+        _, uni = _evenodd_areas(pa, None)      # the same quad twice (nms.h:198/201)
+        inter = uni
+    else:
+        inter, uni = _evenodd_areas(pa, pb)
     inter_f, uni_f = F(inter), F(uni)          # `float area` accumulators of paths_area (:17-22)
     return F(abs(inter_f) / max(abs(uni_f), F(1.0)))
 

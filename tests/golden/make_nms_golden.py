@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle", "_ref", "nms_ref")]
 import adaptor  # noqa: E402  the reference's extension module
-from nms_cases import CASES, synth_maps  # noqa: E402
+from nms_cases import CASES, NUM_HARD, hard_case, quad_class, synth_maps  # noqa: E402
 
 out = {}
 for name, (h, w), words, seed, noise in CASES:
@@ -28,4 +28,19 @@ for name, (h, w), words, seed, noise in CASES:
     out[name + "_crc"] = np.int64(zlib.crc32(segm.tobytes() + geo.tobytes() + ang.tobytes()))
     out[name + "_pixels"] = np.int32((segm > 0.5).sum())
     print(name, (h, w), "pixels", int(out[name + "_pixels"]), "boxes", len(ret))
+# round 3: maps that provoke the clipper's hard cases (merged quads that are not convex / not simple),
+# other thresholds; what the reference's build (its vendored Clipper, even-odd fill) returns for them
+shapes = [0, 0, 0]
+for i in range(NUM_HARD):
+    segm, geo, ang, thr, iou1, iou2 = hard_case(i)
+    h, w = segm.shape
+    angle_hw2 = np.ascontiguousarray(ang.swapaxes(0, 1).swapaxes(1, 2))
+    ret = np.array(adaptor.do_nms(segm, geo, angle_hw2, np.full((h, w), -1, np.int32), iou1, iou2, thr), dtype="float32").reshape(-1, 9)
+    if len(ret) > 0:
+        ret[:, :8] /= 10000
+    out["hard%d_boxes" % i] = ret
+    out["hard%d_crc" % i] = np.int64(zlib.crc32(segm.tobytes() + geo.tobytes() + ang.tobytes()))
+    for b in ret:
+        shapes[quad_class(b[:8])] += 1
+print("hard cases: boxes convex / concave / self-intersecting:", shapes)
 np.savez_compressed(os.path.join(HERE, "nms_cases.npz"), **out)

@@ -28,9 +28,17 @@ def test_bench_self_launches_two_ranks():
     assert r["n_gpus"] == 2 and r["steps"] == 20 and r["warmup"] == 5 and r["scaling"] == "weak"
     assert r["config"]["rois_total"] == 1024 and r["config"]["rois_per_gpu"] == 512
     assert r["value"] > 0 and abs(r["value"] - 1024 / (r["ms_per_step"] * 1e-3)) < 1e-3 * r["value"]
-    assert "with_gather_ms" in r["extra"]
+    ex = r["extra"]
+    assert "with_gather_ms" in ex and "with_allreduce_grad_ms" in ex
+    # the line verifies itself: every rank reports what it ran on and its own time
+    assert len(ex["ranks"]) == 2 and [q["rank"] for q in ex["ranks"]] == [0, 1]
+    for q in ex["ranks"]:
+        assert q["arch"].startswith("gfx") and q["uuid"] and q["ms_per_step"] > 0
+    assert max(q["ms_per_step"] for q in ex["ranks"]) <= r["ms_per_step"] * 1.001
+    assert ex["with_allreduce_grad_ms"] is not None and ex["with_allreduce_grad_ms"] > 0, ex.get("with_allreduce_grad")
     if torch.cuda.device_count() >= 2:
-        assert r["extra"]["with_gather_ms"] > r["ms_per_step"]
+        assert ex["with_gather_ms"] > r["ms_per_step"]
+        assert len({q["uuid"] for q in ex["ranks"]}) == 2
 
 
 def test_bench_refuses_more_gpus_than_visible_without_the_self_test_switch():

@@ -411,6 +411,62 @@ def test_reference_launchers_take_the_fast_paths(ext, oracle):
     assert st == 1 and eq(out.cpu().numpy(), want)
 
 
+def test_reference_launchers_reuse_their_scratch_and_accumulate(ext, oracle):
+    """VERDICT r02 #6 / ADVICE r02: the launchers keep one scratch buffer per (device, stream) inside the
+    library -- no hipMallocAsync / hipFreeAsync per call, so a call whose buffer exists can be captured
+    into a HIP graph -- and `RROIAlignBackwardLaucher` ADDS into bottom_diff on every path, like the
+    reference's atomicAdds (kernel.cu:260-274): the result no longer depends on the problem size."""
+    stream = lambda: torch.cuda.current_stream().cuda_stream
+    for R, C in ((96, 64), (6, 8)):     # above the tiled crossovers / below them (literal kernels)
+        f, r = Wk.bench_inputs(R=R, C=C, seed=31)
+        F, Rr = dev(f), dev(r)
+        shape = (R, C, 8, 64)
+        out, ix, iy = (torch.empty(shape, device="cuda") for _ in range(3))
+        assert ext.rroi_align_forward_cuda(8, 64, 0.25, F, Rr, out, ix, iy) == 1
+        want, wx, wy = oracle.forward_literal_c(f, r, 8, 64, 0.25)
+        assert eq(out.cpu().numpy(), want)
+        gout = torch.randn(shape, device="cuda")
+        wb = oracle.backward_literal_c(gout.cpu().numpy(), r, wx, wy, f.shape, 0.25)
+        scale = max(1.0, float(np.abs(wb).max()))
+        gin = torch.zeros(f.shape, device="cuda")
+        for k in (1, 2, 3):             # three calls onto the same buffer: k times the gradient
+            assert ext.rroi_align_backward_cuda(8, 64, 0.25, gout, Rr, gin, ix, iy) == 1
+            assert np.abs(gin.cpu().numpy() - k * wb).max() <= 3 * BWD_RTOL * scale, (R, k)
+    # capture: the buffers of this stream exist after a first call on it, so the calls enqueue kernels only
+    f, r = Wk.bench_inputs(R=96, C=64, seed=32)
+    F, Rr = dev(f), dev(r)
+    out = torch.empty((96, 64, 8, 64), device="cuda")
+    gin = torch.zeros(f.shape, device="cuda")
+    gout = torch.randn_like(out)
+
+    def calls():
+        assert ext._lib.RROIAlignForwardLaucher(F.data_ptr(), 0.25, 96, 160, 160, 64, 8, 64, Rr.data_ptr(),
+                                                out.data_ptr(), None, None, stream()) == 1
+        assert ext._lib.RROIAlignBackwardLaucher(gout.data_ptr(), 0.25, 1, 96, 160, 160, 64, 8, 64, Rr.data_ptr(),
+                                                 gin.data_ptr(), out.data_ptr(), out.data_ptr(), stream()) == 1
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        calls()                          # creates the side stream's scratch
+        side.synchronize()
+        want_out, g1 = out.clone(), gin.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            calls()
+    torch.cuda.current_stream().wait_stream(side)
+    out.zero_()
+    gin.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want_out)
+    assert float((gin - g1).abs().max()) <= BWD_RTOL * max(1.0, float(g1.abs().max()))
+    ext.release_workspaces()            # frees the library's buffers too; the next call re-creates them
+    assert ext._lib.RROIAlignForwardLaucher(F.data_ptr(), 0.25, 96, 160, 160, 64, 8, 64, Rr.data_ptr(),
+                                            out.data_ptr(), None, None, stream()) == 1
+    torch.cuda.synchronize()
+    assert torch.equal(out, want_out)
+
+
 def test_channels_last_odd_chunk(ext, oracle):
     """C % 32 != 0 with channels-last features consumed in place -- the lanes of the
     channel quads beyond C must fetch nothing (their offset is an out-of-range sentinel that may not

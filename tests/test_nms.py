@@ -10,7 +10,7 @@ import zlib
 import numpy as np
 import pytest
 
-from nms_cases import CASES, synth_maps
+from nms_cases import CASES, NUM_HARD, hard_case, hard_maps, quad_class, synth_maps
 from oracle import nms_oracle as NO
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nms_cases.npz")
@@ -78,6 +78,57 @@ def test_host_merge_equals_reference_build_on_random_maps():
             want[:, :8] /= 10000
         got = merge(_records(NO.decode(segm, geo, a_hw2, thr)), w, h)
         assert got.shape == want.shape and np.array_equal(got, want), (trial, h, w, thr)
+
+
+def test_hard_cases_non_convex_and_self_intersecting_quads():
+    """the reference intersects / unions arbitrary paths with Clipper (pftEvenOdd,
+    nms.h:24-36), and merged quads -- per-coordinate weighted means with different weights for X and Y,
+    nms.h:87-96 -- need not stay convex or simple.  32 frozen maps built to get there (heavy noise, words
+    on top of each other at other angles, thresholds 0.3 ... 0.9; the reference's own build returned 7
+    concave and 19 self-intersecting boxes for them): the product's host merge reproduces every box bit for
+    bit, and so does the restatement on the small ones.  Round 2's Sutherland-Hodgman clipper failed 21 %
+    of such maps (tools/fuzz_nms.py: 63 of 300)."""
+    from rroi_align.nms import merge
+    z = np.load(GOLD)
+    shapes = [0, 0, 0]
+    for i in range(NUM_HARD):
+        segm, geo, ang, thr, iou1, iou2 = hard_case(i)
+        assert zlib.crc32(segm.tobytes() + geo.tobytes() + ang.tobytes()) == int(z["hard%d_crc" % i]), "generator drifted"
+        want = z["hard%d_boxes" % i]
+        a_hw2 = ang.swapaxes(0, 1).swapaxes(1, 2)
+        polys = NO.decode(segm, geo, a_hw2, thr)
+        got = merge(_records(polys), segm.shape[1], segm.shape[0], iou1, iou2)
+        assert got.shape == want.shape and np.array_equal(got, want), i
+        if len(polys) <= 400:                       # the pure-Python restatement: small candidate lists only
+            ref = NO.merge_iou(polys, segm.shape[1], segm.shape[0], iou1, iou2)
+            mine = np.array([[c for v in p["poly"] for c in v] + [p["score"]] for p in ref], np.float32).reshape(-1, 9)
+            mine[:, :8] /= 10000                    # in fp32, as nms/__init__.py:27 does
+            assert np.array_equal(mine, want), i
+        for b in want:
+            shapes[quad_class(b[:8])] += 1
+    assert shapes[1] >= 5 and shapes[2] >= 10, shapes   # the hard cases were reached
+
+
+def test_host_merge_equals_reference_build_on_hard_random_maps():
+    """The same live: 250 more hard maps against the reference's own build run on the spot."""
+    from rroi_align.nms import merge
+    adaptor = _reference_adaptor()
+    rng = np.random.default_rng(2024)
+    odd = 0
+    for trial in range(250):
+        h, w = int(rng.integers(16, 72)), int(rng.integers(24, 120))
+        noise = float(rng.choice([0.0, 0.2, 0.5, 1.0, 2.0]))
+        thr = float(rng.choice([0.3, 0.5, 0.7, 0.9]))
+        iou1, iou2 = float(rng.choice([0.1, 0.3, 0.4, 0.6])), float(rng.choice([0.05, 0.2, 0.5]))
+        segm, geo, ang = hard_maps(h, w, int(rng.integers(1, 10)), rng, noise, float(rng.choice([0.0, 0.5, 0.9])))
+        a_hw2 = np.ascontiguousarray(ang.swapaxes(0, 1).swapaxes(1, 2))
+        want = np.array(adaptor.do_nms(segm, geo, a_hw2, np.full((h, w), -1, np.int32), iou1, iou2, thr), dtype="float32").reshape(-1, 9)
+        if len(want):
+            want[:, :8] /= 10000
+        got = merge(_records(NO.decode(segm, geo, a_hw2, thr)), w, h, iou1, iou2)
+        assert got.shape == want.shape and np.array_equal(got, want), (trial, h, w, noise, thr, iou1, iou2)
+        odd += sum(quad_class(b[:8]) > 0 for b in want)
+    assert odd >= 50, odd
 
 
 def test_merge_statement_quirks():
