@@ -732,7 +732,10 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
     // ... with four chunks per lane (C <= 128) it still wins where the lists are short: C = 128, 160x160,
     // 8x64: R = 32 33 / 42, 128 48 / 48, 512 101 / 93;  C = 96, 176x320, 11x96: 38 / 45, 56 / 61, 114 / 122
     const bool short_lists = (double)num_rois * NB <= 8.0 * (double)batch_size * HW;   // bins per map pixel
-    const bool prefer_inkernel = nchunks <= 2 || (nchunks <= 4 && short_lists);
+    // every map tile's workgroup scans ALL the ROIs (in batches of 256): O(tiles x R), measured up to R = 512
+    // and 8 images -- beyond that the lists in HBM, whose cost does not grow that way, are the safe choice
+    const bool scan_ok = (double)num_rois * batch_size <= 8192.0;
+    const bool prefer_inkernel = scan_ok && (nchunks <= 2 || (nchunks <= 4 && short_lists));
     const bool lists = path == RROI_PATH_TILED_LISTS || !inkernel_ok ||
                        (path != RROI_PATH_TILED_INKERNEL && !prefer_inkernel);
     {
@@ -951,8 +954,21 @@ int rroi_rbox_decode_hip(const float* segm, const float* rbox, const float* angl
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (height <= 0 || width <= 0 || capacity < 0 || (long)height * width >= (1L << 30)) return 0;
     if (!segm || !rbox || !angle || !count || (capacity > 0 && !candidates)) return 0;
-    hipLaunchKernelGGL(rroi_rbox_decode_kernel, dim3(1), dim3(1024), 0, stream, segm, rbox, angle, height, width,
-                       segm_thresh, static_cast<NmsCandidate*>(candidates), capacity, count);
+    const int hw = height * width;
+    const int slabs = ceil_div(hw, 1024);
+    unsigned* slab_counts = nullptr;
+    if (slabs > 256) {
+        // large map: per-slab counts from a first launch, kept behind the records the caller's buffer holds
+        // (capacity * 64 bytes are the caller's; the counts need room of their own: the tail of the records
+        // beyond what can ever be used -- a map of hw pixels yields at most hw records)
+        if ((long)capacity < (long)hw + ceil_div((long)slabs * 4, 64)) return 0;
+        slab_counts = reinterpret_cast<unsigned*>(static_cast<NmsCandidate*>(candidates) + hw);
+        hipLaunchKernelGGL(rroi_rbox_count_kernel, dim3(slabs), dim3(1024), 0, stream, segm, hw, segm_thresh, slab_counts);
+        const int st = launch_status();
+        if (st != 1) return st;
+    }
+    hipLaunchKernelGGL(rroi_rbox_decode_kernel, dim3(slabs), dim3(1024), 0, stream, segm, rbox, angle, height, width,
+                       segm_thresh, static_cast<NmsCandidate*>(candidates), slab_counts ? hw : capacity, count, slab_counts);
     return launch_status();
 }
 

@@ -102,7 +102,17 @@ __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float*
         if (!PIXMAJOR) return t + tile_stride;
         return (t + 1) % nchunks ? t + 1 : t + 1 - nchunks + tile_stride;
     };
-    if (tile < relayout_tiles) load_tile(tile);
+    // gfx950 counts loads and stores with ONE in-order vmcnt.  Inside the loop the tile in `r` was loaded
+    // BEFORE the previous tile's four stores were issued, so waiting for it needs vmcnt(4), not vmcnt(0) --
+    // but the compiler takes the most conservative count over the paths that reach the loop head, and on
+    // the way in there are no stores yet: it emitted vmcnt(0), and every tile waited for the previous
+    // tile's stores to be acknowledged.  Four stores that go nowhere make the two paths alike.
+    if (tile < relayout_tiles) {
+        load_tile(tile);
+        const __amdgpu_buffer_rsrc_t nowhere = make_rsrc(cm, 0u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) buf_store<AUX>(nowhere, kOOB + 16u * j, v4f{0.f, 0.f, 0.f, 0.f});  // four distinct stores
+    }
     while (tile < relayout_tiles) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -133,15 +143,12 @@ __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float*
                 const unsigned y = fdiv(gp, div_w);
                 const unsigned x = gp - y * (unsigned)width;
                 const size_t pix = (size_t)y * pitch + x;
-                if (p0 + p < HW && !(MASK && (float)x > lim)) {
-                    if (AUX == 0) {
-                        *reinterpret_cast<v4f*>(dst + pix * px_floats + cq * 4) = v;
-                    } else {
-                        const __amdgpu_buffer_rsrc_t ws =
-                            make_rsrc(dst, PIXMAJOR ? (unsigned)(img_bytes - (size_t)k * kLineBytes) : (unsigned)(slice_stride * 4));
-                        buf_store<AUX>(ws, (unsigned)((pix * px_floats + cq * 4) * 4), v);
-                    }
-                }
+                // every wave issues its four stores on every path (a pixel that is not written is an
+                // out-of-range offset, dropped by the descriptor check): see the note on s_waitcnt below
+                const bool ok = p0 + p < HW && !(MASK && (float)x > lim);
+                const __amdgpu_buffer_rsrc_t ws =
+                    make_rsrc(dst, PIXMAJOR ? (unsigned)(img_bytes - (size_t)k * kLineBytes) : (unsigned)(slice_stride * 4));
+                buf_store<AUX>(ws, ok ? (unsigned)((pix * px_floats + cq * 4) * 4) : kOOB, v);
             }
         }
         __syncthreads();

@@ -12,8 +12,12 @@
 // corner confidences, the pixel -- written in RASTER ORDER (the merge depends on it), and only
 // those records cross to the host.  Channels-first inputs, as the network emits them: no transposes.
 //
-// One workgroup walks the map 1024 pixels at a time and carries the running count: the map is
-// small (176 x 320 at 1280 x 704) and the order is free that way.
+// Ordered compaction over many workgroups (round 3; round 2 walked the map with ONE workgroup): workgroup
+// i owns pixels [1024 i, 1024 i + 1024) and needs the number of passing pixels before them.  It counts
+// them itself -- a 16-byte load per thread covers 4096 pixels of the score map per step, the whole
+// 176 x 320 map of a 1280 x 704 image in 14 steps, out of L2 -- so there is no second launch, no flag
+// chain between workgroups and no counter that somebody would have to clear.  (Maps beyond 256 K pixels,
+// where the redundant counting would cost more than a launch, take per-slab counts from a first launch.)
 // fp32 arithmetic exactly as adaptor.cpp writes it (-ffp-contract=off); the corner confidences
 // use exp in double rounded once, the C library's expf the reference calls agrees with that except
 // for an occasional last place (the quads do not depend on it).
@@ -27,17 +31,56 @@ struct NmsCandidate {  // 64 bytes
 };
 static_assert(sizeof(NmsCandidate) == 64, "one candidate = one 64-byte record");
 
+// number of pixels of segm[lo, hi) above the threshold, counted by the whole workgroup (1024 threads)
+__device__ __forceinline__ unsigned nms_count_passing(const float* __restrict__ segm, int lo, int hi, float thr,
+                                                      unsigned* wave_total)
+{
+    const unsigned tid = threadIdx.x;
+    unsigned n = 0;
+    const bool vec = (reinterpret_cast<uintptr_t>(segm) & 15) == 0;
+    int p = lo;
+    if (vec) {
+        for (; p + 4096 <= hi; p += 4096) {
+            const v4f v = *reinterpret_cast<const v4f*>(segm + p + 4 * (int)tid);
+            n += (v.x > thr) + (v.y > thr) + (v.z > thr) + (v.w > thr);
+        }
+    }
+    for (; p < hi; p += 1024) n += (p + (int)tid < hi && segm[p + (int)tid] > thr) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) n += __shfl_xor(n, o);
+    if ((tid & 63u) == 0) wave_total[tid >> 6] = n;
+    __syncthreads();
+    unsigned total = 0;
+    for (unsigned k = 0; k < 16; ++k) total += wave_total[k];
+    __syncthreads();
+    return total;
+}
+
+// slab_counts == nullptr: count the pixels before this slab here; else slab_counts[j] = passing pixels of slab j
 __global__ __launch_bounds__(1024) void rroi_rbox_decode_kernel(
     const float* __restrict__ segm, const float* __restrict__ rbox, const float* __restrict__ angle, int h, int w,
-    float segm_thresh, NmsCandidate* __restrict__ out, int capacity, int* __restrict__ count)
+    float segm_thresh, NmsCandidate* __restrict__ out, int capacity, int* __restrict__ count,
+    const unsigned* __restrict__ slab_counts)
 {
     __shared__ unsigned wave_total[16];
-    __shared__ unsigned base_s;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const int hw = h * w;
-    if (tid == 0) base_s = 0;
-    __syncthreads();
-    for (int p0 = 0; p0 < hw; p0 += 1024) {
+    const int p0 = (int)blockIdx.x * 1024;
+    unsigned base;
+    if (slab_counts) {
+        unsigned n = 0;
+        for (unsigned j = tid; j < blockIdx.x; j += 1024) n += slab_counts[j];
+#pragma unroll
+        for (int o = 32; o; o >>= 1) n += __shfl_xor(n, o);
+        if (lane == 0) wave_total[wv] = n;
+        __syncthreads();
+        base = 0;
+        for (unsigned k = 0; k < 16; ++k) base += wave_total[k];
+        __syncthreads();
+    } else {
+        base = nms_count_passing(segm, 0, p0, segm_thresh, wave_total);
+    }
+    {
         const int p = p0 + (int)tid;
         const bool pass = p < hw && segm[p] > segm_thresh;
         const unsigned long long m = __ballot(pass);
@@ -49,11 +92,12 @@ __global__ __launch_bounds__(1024) void rroi_rbox_decode_kernel(
             if (k < wv) before += v;
             total += v;
         }
-        const unsigned slot = base_s + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        const unsigned slot = base + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
         if (pass && slot < (unsigned)capacity) {
             const int y = p / w, x = p - y * w;
-            const float r0 = rbox[p], r1 = rbox[hw + p], r2 = rbox[2 * hw + p], r3 = rbox[3 * hw + p];
-            const float angle_sin = angle[p], angle_cos = angle[hw + p];   // a[0], a[1] (:84-85)
+            const size_t q = (size_t)p, n = (size_t)hw;
+            const float r0 = rbox[q], r1 = rbox[n + q], r2 = rbox[2 * n + q], r3 = rbox[3 * n + q];
+            const float angle_sin = angle[q], angle_cos = angle[n + q];   // a[0], a[1] (:84-85)
             const float scale_factor = 4.0f, precision = 10000.0f;
             const float xp = (float)x + 0.25f, yp = (float)y + 0.25f;
             const float pos_r_x = (xp - r2 * angle_cos) * scale_factor;
@@ -81,9 +125,17 @@ __global__ __launch_bounds__(1024) void rroi_rbox_decode_kernel(
             c.pad = 0;
             out[slot] = c;
         }
-        __syncthreads();
-        if (tid == 0) base_s += total;
-        __syncthreads();
+        // the workgroup of the last slab knows the total; it may exceed `capacity`: the caller sees how many there were
+        if (blockIdx.x == gridDim.x - 1 && tid == 0) *count = (int)(base + total);
     }
-    if (tid == 0) *count = (int)base_s;  // may exceed `capacity`: the caller sees how many there were
+}
+
+// maps beyond 256 K pixels: passing pixels per 1024-pixel slab (the decode launch then sums the slabs before its own)
+__global__ __launch_bounds__(1024) void rroi_rbox_count_kernel(const float* __restrict__ segm, int hw, float segm_thresh,
+                                                              unsigned* __restrict__ slab_counts)
+{
+    __shared__ unsigned wave_total[16];
+    const int p0 = (int)blockIdx.x * 1024;
+    const unsigned total = nms_count_passing(segm, p0, min(hw, p0 + 1024), segm_thresh, wave_total);
+    if (threadIdx.x == 0) slab_counts[blockIdx.x] = total;
 }

@@ -45,13 +45,21 @@ class GroundTruthRRoiAlign(Module):
     """The training caller's call (src/ocr_process.py:196-221, :253-267): ground-truth quads of a
     batch -> crops for the recognition loss, ROI rows and pooled width computed on the device.
 
-    forward(features, quads, batch_index, height_jitter=None) -> (crops (N, C, pooled_height, pooled_width), rois)
+    forward(features, quads, batch_index, height_jitter=None, keep=None)
+        -> (crops (N, C, pooled_height, pooled_width), rois)
     with pooled_width = ceil(pooled_height * max(w / h)) (:260-263) read back once, as the
-    reference does with `.item()`.  `height_jitter` is the caller's random.randint(-2, 2) (:204), one
-    value per box (the reference draws one per image).  Rows whose jittered h is negative yield
-    all-zero crops (the op's `pw <= roi_pooled_width` mask is false everywhere, kernel.cu:107); an
-    h of exactly 0 makes the ratio infinite -- the reference's `math.ceil` raises there, and so does
-    this module.  The reference truncates to the first 32 rows (:253-255): `max_rois`.
+    reference does with `.item()`.
+
+    What stays with the caller, as in the reference: WHICH boxes take part.  The reference drops boxes
+    whose label starts with '##' and boxes that leave the image (:212-219) and only then truncates the
+    list of the whole batch to its first 32 rows (:253-255).  Pass the surviving boxes, or all of them
+    with `keep` (N,) bool: the filter is applied first, `max_rois` second -- the reference's order.
+    `height_jitter` is the caller's random.randint(-2, 2) (:204): one value per box, or -- what the
+    reference draws -- ONE PER IMAGE, a tensor of batch-size length that is then looked up through
+    `batch_index`.  Rows whose jittered h is negative yield all-zero crops (the op's
+    `pw <= roi_pooled_width` mask is false everywhere, kernel.cu:107); an h of exactly 0 makes the ratio
+    infinite -- the reference's `math.ceil` raises there, and so does this module.  A maximal ratio
+    <= 0 (every w = 0) would make the reference's pooled width 0 (and its launch fail); it is 1 here.
     """
 
     def __init__(self, pooled_height=11, spatial_scale=1.0 / 4, max_rois=32):
@@ -60,8 +68,18 @@ class GroundTruthRRoiAlign(Module):
         self.spatial_scale = float(spatial_scale)
         self.max_rois = max_rois
 
-    def forward(self, features, quads, batch_index=None, height_jitter=None):
+    def forward(self, features, quads, batch_index=None, height_jitter=None, keep=None):
         import math
+        n = quads.shape[0]
+        if height_jitter is not None and height_jitter.numel() != n:
+            if batch_index is None:
+                raise ValueError("a per-image height_jitter needs batch_index")
+            height_jitter = height_jitter.reshape(-1)[batch_index.reshape(-1).long()]
+        if keep is not None:
+            keep = keep.reshape(-1).bool()
+            quads = quads[keep]
+            batch_index = None if batch_index is None else batch_index.reshape(-1)[keep]
+            height_jitter = None if height_jitter is None else height_jitter.reshape(-1)[keep]
         if self.max_rois is not None:
             quads = quads[: self.max_rois]
             batch_index = None if batch_index is None else batch_index[: self.max_rois]

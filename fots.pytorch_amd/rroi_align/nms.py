@@ -27,11 +27,14 @@ def decode(score, rbox, angle, segm_thresh=0.5):
         _ext._require_cuda_f32(t, name)
     h, w = score.shape[-2:]
     score, rbox, angle = score.reshape(h, w).contiguous(), rbox.reshape(4, h, w).contiguous(), angle.reshape(2, h, w).contiguous()
+    slabs = (h * w + 1023) // 1024
+    # maps beyond 256 K pixels: the library keeps its per-slab counts behind the h * w records
+    cap = h * w + ((slabs * 4 + 63) // 64 if slabs > 256 else 0)
     with torch.cuda.device_of(score):
-        rec = torch.empty((h * w, 64), dtype=torch.uint8, device=score.device)
+        rec = torch.empty((cap, 64), dtype=torch.uint8, device=score.device)
         cnt = torch.empty((1,), dtype=torch.int32, device=score.device)
         st = _ext._lib.rroi_rbox_decode_hip(score.data_ptr(), rbox.data_ptr(), angle.data_ptr(), h, w,
-                                            float(segm_thresh), rec.data_ptr(), h * w, cnt.data_ptr(), _ext._stream())
+                                            float(segm_thresh), rec.data_ptr(), cap, cnt.data_ptr(), _ext._stream())
     _ext._check(st, "rroi_rbox_decode_hip")
     return rec, cnt
 

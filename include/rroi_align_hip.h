@@ -177,7 +177,9 @@ int rroi_align_gt_quads_to_rois_hip(const float* quads, const float* batch_index
  *        1/10000 px, float score, float probs[4], int32 x, y, pad (adaptor.cpp:76-117).
  *        rbox (4, h, w) and angle (2, h, w) are CHANNELS-FIRST, as the network emits them
  *        (the reference transposes on the host first).  *count receives the number of passing
- *        pixels even when it exceeds `capacity` (records beyond it are dropped).
+ *        pixels even when it exceeds `capacity` (records beyond it are dropped).  One workgroup per
+ *        1024 pixels; a map of more than 262144 pixels needs `capacity` >= h * w + ceil(h * w / 1024
+ *        / 16) records (the library keeps its per-slab counts behind the h * w records it can fill).
  *    rroi_nms_merge_host     host (no GPU work): locality-aware merge with `iou_threshold`, then
  *        polygon NMS with `iou_threshold2` (the reference passes 0.4 and 0.2) over `num_candidates`
  *        records in host memory -> boxes (n, 9) fp32 [x0,y0,..,x3,y3 in px, score]; returns the

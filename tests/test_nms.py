@@ -173,3 +173,35 @@ def test_device_decode_and_get_boxes(case):
     assert np.allclose(boxes[:, 8], ref[:, 8], rtol=1e-6)
     # the reference's call-site layout (numpy, rbox as (h, w, 4)) gives the same boxes
     assert np.array_equal(N.get_boxes(segm, geo, ang, 0.5), boxes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(40, 70), (176, 320), (600, 610)])
+def test_device_decode_is_ordered_over_many_workgroups(shape):
+    """Round 3: the decode runs one workgroup per 1024 pixels (round 2: one workgroup for the whole map);
+    the records still come out in raster order -- the merge depends on it -- also on a map large enough
+    (> 262144 pixels) for the two-launch path with per-slab counts."""
+    import torch
+    from rroi_align import nms as N
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    segm = (rng.random((h, w)) * 0.52).astype(np.float32)        # ~4 % of the pixels pass
+    geo = rng.uniform(0, 12, (h, w, 4)).astype(np.float32)
+    a = rng.uniform(-1.5, 1.5, (h, w))
+    ang = np.stack([np.sin(a), np.cos(a)]).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    S, G, A = torch.from_numpy(segm).to(dev), torch.from_numpy(geo.transpose(2, 0, 1).copy()).to(dev), torch.from_numpy(ang).to(dev)
+    rec, cnt = N.decode(S, G, A, 0.5)
+    n = int(cnt.item())
+    ys, xs = np.nonzero(segm > 0.5)                                # raster order
+    assert n == len(ys) > 0
+    got = rec[:n].cpu().numpy().view(N.CANDIDATE).reshape(-1)
+    assert np.array_equal(got["y"], ys) and np.array_equal(got["x"], xs)
+    assert np.array_equal(got["score"], segm[ys, xs])
+    # quads of a sample of the records against the restatement
+    sub = np.zeros_like(segm)
+    pick = rng.choice(n, min(n, 300), replace=False)
+    sub[ys[pick], xs[pick]] = segm[ys[pick], xs[pick]]
+    want = _records(NO.decode(sub, geo, ang.swapaxes(0, 1).swapaxes(1, 2), 0.5))
+    sel = np.sort(pick)
+    assert np.array_equal(got["quad"][sel], want["quad"])

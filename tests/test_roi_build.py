@@ -136,6 +136,17 @@ def test_ground_truth_module_and_degenerate_jitter(oracle):
     jit[3] = -1.0                                                              # h == 0 -> w / h = inf
     with pytest.raises(ValueError):
         m(feats, torch.from_numpy(q).cuda(), torch.from_numpy(bidx).cuda(), torch.from_numpy(jit).cuda())
+    # the reference's own order -- filter ('##' labels, boxes that leave the image, :212-219),
+    # THEN keep 32 rows (:253-255) -- and its one jitter draw PER IMAGE (:204), looked up through batch_index
+    keep = np.ones(40, bool)
+    keep[[0, 3, 5, 17]] = False
+    per_image = np.asarray([2.0, -1.0], np.float32)
+    crops2, rois2 = m(feats, torch.from_numpy(q).cuda(), torch.from_numpy(bidx).cuda(), torch.from_numpy(per_image).cuda(),
+                      keep=torch.from_numpy(keep).cuda())
+    want2, _ = RB.rois_from_quads(q[keep][:32], bidx[keep][:32], mode=1, jitter=per_image[bidx.astype(int)][keep][:32])
+    assert np.array_equal(rois2.cpu().numpy(), want2) and rois2.shape[0] == 32
+    pw2 = RB.train_pooled_width(want2)
+    assert np.array_equal(crops2.cpu().numpy(), oracle.forward_c(feats_np, want2, 11, pw2, 0.25, threads=8))
 
 
 @pytest.mark.gpu
