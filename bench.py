@@ -206,6 +206,9 @@ def run(args):
     launch(ext.STAGE_ALL)
     gather_ms = event_loop(lambda: launch(ext.STAGE_GATHER), KERNEL_WARM, KERNEL_TIMED)
     prologue_ms = event_loop(lambda: launch(ext.STAGE_PROLOGUE), 100, 200)
+    # the whole call by the same clock (two HIP events around back-to-back calls): a second, independent
+    # reading of the step next to the wall-clock one below, and the state the timed region starts from
+    step_events_ms = event_loop(lambda: launch(ext.STAGE_ALL), 100, 300)
 
     # ---- the metric: W untimed warm-up steps, then exactly K timed steps --------------------------
     for _ in range(args.warmup):
@@ -392,6 +395,7 @@ def run(args):
                                           "launches (includes the ~1 us launch-to-launch gap the rocprofv3 "
                                           "kernel trace does not)" % (KERNEL_TIMED, KERNEL_WARM)},
                      "prologue_ms_avg": round(prologue_ms, 5),
+                     "whole_call_ms_events": round(step_events_ms, 5),
                      "calibrated": {"what": "torch fill_ of the 256 MiB output buffer on this GPU (40 back-to-back)",
                                     "GB/s": round(fill_gbs, 1), "frac_of_it": round(achieved / fill_gbs, 4)}},
         "cpu_baseline": cpu,

@@ -398,7 +398,8 @@ int rroi_align_forward_hip(const float* features, int feature_layout, float spat
 static int forward_impl(const float* features, int feature_layout, int top_layout, float spatial_scale,
                         int batch_size, int num_rois, int height, int width, int channels,
                         int pooled_height, int pooled_width, const float* rois, float* top_data,
-                        void* workspace, size_t workspace_bytes, int path, int stages, void* stream_);
+                        void* workspace, size_t workspace_bytes, int path, int stages, void* stream_,
+                        bool launcher_rest = false);
 
 int rroi_align_forward_stages_hip(const float* features, int feature_layout, float spatial_scale,
                                   int batch_size, int num_rois, int height, int width,
@@ -422,10 +423,13 @@ int rroi_align_forward_layout_hip(const float* features, int feature_layout, int
                         workspace_bytes, path, RROI_STAGE_ALL, stream_);
 }
 
+// launcher_rest (the reference-ABI launcher; tiled NCHW path): ROIs whose image index is >= batch_size are
+// sampled from the NCHW tensor by extra blocks of the prologue launch and left alone by the gather
 static int forward_impl(const float* features, int feature_layout, int top_layout, float spatial_scale,
                         int batch_size, int num_rois, int height, int width, int channels,
                         int pooled_height, int pooled_width, const float* rois, float* top_data,
-                        void* workspace, size_t workspace_bytes, int path, int stages, void* stream_)
+                        void* workspace, size_t workspace_bytes, int path, int stages, void* stream_,
+                        bool launcher_rest)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if ((stages & ~RROI_STAGE_ALL) || stages == 0) return 0;
@@ -460,7 +464,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         direct_grid(num_rois, NB, channels, grid, cslab);
         hipLaunchKernelGGL(rroi_fwd_direct_kernel, grid, dim3(256), 0, stream, features, rois,
                            top_data, (float*)nullptr, (float*)nullptr, num_rois, channels, height,
-                           width, pooled_height, pooled_width, spatial_scale, batch_size, cslab, 0);
+                           width, pooled_height, pooled_width, spatial_scale, batch_size, cslab);
         return launch_status();
     }
 
@@ -487,12 +491,15 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         }
         const int zero_blocks = zero_copy ? 0 : ceil_div((long)batch_size * nchunks * kChunk, 256);
         const int aff_blocks = ceil_div(num_rois, 256);
+        const int rest_blocks = launcher_rest ? num_rois : 0;
 #define RROI_LAUNCH_PRO(AUX)                                                                        \
-    hipLaunchKernelGGL(rroi_prologue_kernel<AUX>, dim3(relayout_blocks + zero_blocks + aff_blocks),   \
-                       dim3(256), 0, stream, features, ws.cm, channels, HW, width, pitch,             \
+    hipLaunchKernelGGL(rroi_prologue_kernel<AUX>,                                                     \
+                       dim3(relayout_blocks + zero_blocks + aff_blocks + rest_blocks), dim3(256), 0,  \
+                       stream, features, ws.cm, channels, HW, width, pitch,                           \
                        make_fastdiv((unsigned)width), nchunks, ptiles, relayout_blocks,               \
                        relayout_tiles, zero_blocks, batch_size, rois, num_rois, pooled_height,        \
-                       spatial_scale, ws.aff)
+                       spatial_scale, ws.aff, aff_blocks, launcher_rest ? top_data : (float*)nullptr, \
+                       pooled_width)
         if (g_prologue_aux == 16) RROI_LAUNCH_PRO(16);
         else RROI_LAUNCH_PRO(0);
 #undef RROI_LAUNCH_PRO
@@ -526,7 +533,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
 #define RROI_LAUNCH_SPLIT(VEC)                                                                           \
     hipLaunchKernelGGL((rroi_fwd_split_kernel<VEC, 2>), dim3(sgrid), dim3(2 * kWave), 0, stream, map,     \
                        ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size, \
-                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
+                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg | (launcher_rest ? 32 : 0))
         if (out_nhwc)
             hipLaunchKernelGGL((rroi_fwd_tiled_kernel<true, 2, true>), dim3(grid), dim3(kWave), 0, stream, map,
                                ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,
@@ -543,8 +550,8 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         else if (g_fwd_split == 6) RROI_LAUNCH_SPLIT_X(8);
 #undef RROI_LAUNCH_SPLIT_X
 #endif
-        else if (g_fwd_split && g_store_aux == 2 && NB % 4 != 0) RROI_LAUNCH_SPLIT(false);
-        else if (g_fwd_split && g_store_aux == 2) RROI_LAUNCH_SPLIT(true);
+        else if ((g_fwd_split || launcher_rest) && g_store_aux == 2 && NB % 4 != 0) RROI_LAUNCH_SPLIT(false);
+        else if ((g_fwd_split || launcher_rest) && g_store_aux == 2) RROI_LAUNCH_SPLIT(true);
         else if (NB % 4 != 0) RROI_LAUNCH_FWD(false, 2);
         else if (g_store_aux == 0) RROI_LAUNCH_FWD(true, 0);    // exploration only
         else if (g_store_aux == 16) RROI_LAUNCH_FWD(true, 16);  // exploration only
@@ -1042,14 +1049,14 @@ int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
         hipLaunchKernelGGL(rroi_fwd_direct_kernel, grid, dim3(256), 0, stream, bottom_data, bottom_rois,
                            top_data, con_idx_x, con_idx_y, num_rois, channels, height, width,
                            pooled_height, pooled_width, spatial_scale, /*batch_size unknown*/ -1,
-                           cslab, 0);
+                           cslab);
         return launch_status();
     }
     // Tiled path for the ROIs of image 0 (every ROI, in inference and in the benchmark); the
-    // signature does not say how many images `bottom_data` holds, so the ROIs of images >= 1 --
-    // for which the tiled kernels have written zeros -- are then produced by the direct kernel,
-    // which trusts the index as the reference does.  When there are none that launch only reads
-    // the ROI rows.
+    // signature does not say how many images `bottom_data` holds, so the ROIs of images >= 1 are
+    // sampled from the NCHW tensor by one more block per ROI of the prologue launch (trusting the
+    // index as the reference does; a block whose ROI is of image 0 reads the index and leaves) and
+    // skipped by the gather: the same two launches as the native call.
     const size_t bytes = carve(nullptr, 1, channels, height, width, num_rois, RROI_LAYOUT_NCHW).bytes;
     bool transient;
     hipError_t e;
@@ -1057,13 +1064,7 @@ int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
     if (!ws) return status_of(e);
     int st = forward_impl(bottom_data, RROI_LAYOUT_NCHW, RROI_LAYOUT_NCHW, spatial_scale, 1, num_rois, height,
                           width, channels, pooled_height, pooled_width, bottom_rois, top_data, ws, bytes,
-                          RROI_PATH_TILED, RROI_STAGE_ALL, stream_);
-    if (st == 1) {
-        hipLaunchKernelGGL(rroi_fwd_direct_kernel, grid, dim3(256), 0, stream, bottom_data, bottom_rois,
-                           top_data, (float*)nullptr, (float*)nullptr, num_rois, channels, height, width,
-                           pooled_height, pooled_width, spatial_scale, -1, cslab, /*batch_lo*/ 1);
-        st = launch_status();
-    }
+                          RROI_PATH_TILED, RROI_STAGE_ALL, stream_, /*launcher_rest*/ true);
     if (st == 1 && con_idx_x) {
         hipLaunchKernelGGL(rroi_con_idx_kernel, grid, dim3(256), 0, stream, bottom_rois, con_idx_x, con_idx_y,
                            num_rois, channels, height, width, pooled_height, pooled_width, spatial_scale, cslab);

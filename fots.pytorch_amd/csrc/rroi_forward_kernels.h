@@ -155,15 +155,68 @@ __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float*
     }
 }
 
+// one (roi, bin) over the channels [c_begin, c_end): geometry once, then the reference's four taps per channel
+__device__ __forceinline__ void direct_bin(const float* __restrict__ feat, const Affine& A, float* __restrict__ out,
+                                           float* __restrict__ idx_x, float* __restrict__ idx_y, int n, int bin, int C,
+                                           int height, int width, int pooled_width, int NB, int batch_size,
+                                           int c_begin, int c_end)
+{
+    const int ph = bin / pooled_width, pw = bin - ph * pooled_width;
+    float bcx, bcy;
+    const bool in_rroi = bin_centre(A, ph, pw, height, width, bcx, bcy);
+    // batch_size < 0: unknown (reference ABI) -> trust the index like the reference does
+    const bool batch_ok = batch_size < 0 || (A.batch >= 0 && A.batch < batch_size);
+    const bool active = in_rroi && batch_ok;
+    const Taps tp = make_taps(bcx, bcy, active, height, width, 1u);
+    float wlt, wrt, wrb, wlb;
+    tap_weights(tp.rx, tp.ry, wlt, wrt, wrb, wlb);
+    const unsigned f = tp.flags;
+    const unsigned o_lt = tp.o_lt;
+    const unsigned o_rt = o_lt + ((f & kDx) ? 1u : 0u);
+    const unsigned o_lb = o_lt + ((f & kDy) ? (unsigned)width : 0u);
+    const unsigned o_rb = o_lb + ((f & kDx) ? 1u : 0u);
+
+    const size_t HW = (size_t)height * width;
+    const float* plane = feat + ((size_t)(batch_ok ? A.batch : 0) * C + c_begin) * HW;
+    size_t o = ((size_t)n * C + c_begin) * NB + bin;
+    for (int c = c_begin; c < c_end; ++c, plane += HW, o += NB) {
+        float v = 0.0f;
+        if (active) {
+            const float lt = (f & kV00) ? plane[o_lt] : 0.0f;
+            const float rt = (f & kV01) ? plane[o_rt] : 0.0f;
+            const float lb = (f & kV10) ? plane[o_lb] : 0.0f;
+            const float rb = (f & kV11) ? plane[o_rb] : 0.0f;
+            v = blend1(lt, rt, rb, lb, wlt, wrt, wrb, wlb);
+        }
+        out[o] = v;
+        if (idx_x) idx_x[o] = active ? bcx : 0.0f;
+        if (idx_y) idx_y[o] = active ? bcy : 0.0f;
+    }
+}
+
 template <int AUX>
 __global__ __launch_bounds__(256) void rroi_prologue_kernel(
     const float* __restrict__ nchw, float* __restrict__ cm, int C, int HW, int width, int pitch,
     FastDiv div_w, int nchunks, int ptiles, int relayout_blocks, int relayout_tiles, int zero_blocks,
     int batch_size, const float* __restrict__ rois, int num_rois, int pooled_height,
-    float spatial_scale, Affine* __restrict__ aff)
+    float spatial_scale, Affine* __restrict__ aff, int aff_blocks = 0, float* __restrict__ rest_out = nullptr,
+    int pooled_width = 0)
 {
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
     const int tid = threadIdx.x;
+    if (rest_out && (int)blockIdx.x >= relayout_blocks + zero_blocks + aff_blocks) {
+        // The reference-ABI launcher (one more block per ROI).  Its signature does not say how many images
+        // `nchw` holds, so the copy and the tiled gather serve image 0; the ROIs of images >= 1 -- none, as a
+        // rule: the block reads the index and leaves -- are sampled here from the NCHW tensor, trusting the
+        // index as the reference does, and the gather leaves their crops alone.
+        const int n = (int)blockIdx.x - relayout_blocks - zero_blocks - aff_blocks;
+        if (f2i_sat(rois[(size_t)n * 6]) < batch_size) return;
+        const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+        const int NB = pooled_height * pooled_width;
+        for (int bin = tid; bin < NB; bin += 256)
+            direct_bin(nchw, A, rest_out, nullptr, nullptr, n, bin, C, HW / width, width, pooled_width, NB, /*trust*/ -1, 0, C);
+        return;
+    }
     if ((int)blockIdx.x >= relayout_blocks + zero_blocks) {
         const int n = ((int)blockIdx.x - relayout_blocks - zero_blocks) * 256 + tid;
         if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
@@ -774,7 +827,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
 
     // phase C, the storer's: the [rows < C] x [64 bins] tile leaves T for its registers between the two
     // barriers, then goes out as 256-byte row segments (dbg & 1, the ablation knob, drops the stores)
-    auto drain_tile = [&](unsigned n, unsigned t, unsigned long long cur_mask) {
+    auto drain_tile = [&](unsigned n, unsigned t, unsigned long long cur_mask, bool skip) {
         v4f v[kChunk / 4];
 #pragma unroll
         for (int s4 = 0; s4 < kChunk / 4; ++s4) {
@@ -782,7 +835,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             v[s4] = *reinterpret_cast<const v4f*>(T + r * kTStride + (col ^ ((r >> 3) * 4u)));
         }
         wg_lds_barrier();  // T has been read: the gatherer may blend the next tile into it
-        const bool live = !(dbg & 1);
+        const bool live = !(dbg & 1) && !skip;
         // descriptor over this (roi, chunk) block of the output: rows >= C fall out of range
         float* obase = out + ((size_t)n * C + k * kChunk) * NB;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, chans_here * (unsigned)NB * 4u);
@@ -826,20 +879,25 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         unsigned gl, gh;
         unsigned long long mask_cur = 0, mask_prev = 0;
         unsigned n_prev = 0, t_prev = 0;
+        // dbg & 32 (the reference-ABI launcher): the crops of ROIs whose image index is >= batch_size have been
+        // written by the prologue launch -- they are not zero-filled here
+        bool skip_cur = false, skip_prev = false;
         auto plan = [&](unsigned pn, unsigned pt, unsigned pp, unsigned long long& m) {
             const Affine A = aff[pn];
+            skip_cur = (dbg & 32) && A.batch >= batch_size;  // (a negative index still yields zeros)
             geometry(A, pt, pp, gl, gh, m);
             if (lane == 0) shead[pp] = make_uint4(gl, gh, (unsigned)m, (unsigned)(m >> 32));
         };
         plan(n, t, 0, mask_cur);
         for (bool have_prev = false;; have_prev = true) {
             wg_lds_barrier();  // 1: records of item `cur` are in set p; the tile of the previous item is in T
-            if (have_prev) drain_tile(n_prev, t_prev, mask_prev);  // T -> registers | barrier 2 | stores
+            if (have_prev) drain_tile(n_prev, t_prev, mask_prev, skip_prev);  // T -> registers | barrier 2 | stores
             else wg_lds_barrier();
             if (cur >= items) break;
             n_prev = n;
             t_prev = t;
             mask_prev = mask_cur;
+            skip_prev = skip_cur;
             cur += nslots;
             if (cur < items) {
                 n = fdiv(cur, div_tiles);
@@ -940,51 +998,17 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
     const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
     float* __restrict__ idx_x, float* __restrict__ idx_y, int num_rois, int C, int height,
     int width, int pooled_height, int pooled_width, float spatial_scale, int batch_size,
-    int cslab, int batch_lo)
+    int cslab)
 {
     const int NB = pooled_height * pooled_width;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)num_rois * NB) return;
     const int n = (int)(gid / NB);
     const int bin = (int)(gid - (long)n * NB);
-    const int ph = bin / pooled_width, pw = bin - ph * pooled_width;
-
     const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
-    // batch_lo > 0 (reference-ABI launcher): only the ROIs of images >= batch_lo -- the tiled
-    // kernels have already written the others
-    if (batch_lo > 0 && A.batch < batch_lo) return;
-    float bcx, bcy;
-    const bool in_rroi = bin_centre(A, ph, pw, height, width, bcx, bcy);
-    // batch_size < 0: unknown (reference ABI) -> trust the index like the reference does
-    const bool batch_ok = batch_size < 0 || (A.batch >= 0 && A.batch < batch_size);
-    const bool active = in_rroi && batch_ok;
-    const Taps tp = make_taps(bcx, bcy, active, height, width, 1u);
-    float wlt, wrt, wrb, wlb;
-    tap_weights(tp.rx, tp.ry, wlt, wrt, wrb, wlb);
-    const unsigned f = tp.flags;
-    const unsigned o_lt = tp.o_lt;
-    const unsigned o_rt = o_lt + ((f & kDx) ? 1u : 0u);
-    const unsigned o_lb = o_lt + ((f & kDy) ? (unsigned)width : 0u);
-    const unsigned o_rb = o_lb + ((f & kDx) ? 1u : 0u);
-
-    const size_t HW = (size_t)height * width;
     const int c_begin = blockIdx.y * cslab;
-    const int c_end = min(C, c_begin + cslab);
-    const float* plane = feat + ((size_t)(batch_ok ? A.batch : 0) * C + c_begin) * HW;
-    size_t o = ((size_t)n * C + c_begin) * NB + bin;
-    for (int c = c_begin; c < c_end; ++c, plane += HW, o += NB) {
-        float v = 0.0f;
-        if (active) {
-            const float lt = (f & kV00) ? plane[o_lt] : 0.0f;
-            const float rt = (f & kV01) ? plane[o_rt] : 0.0f;
-            const float lb = (f & kV10) ? plane[o_lb] : 0.0f;
-            const float rb = (f & kV11) ? plane[o_rb] : 0.0f;
-            v = blend1(lt, rt, rb, lb, wlt, wrt, wrb, wlb);
-        }
-        out[o] = v;
-        if (idx_x) idx_x[o] = active ? bcx : 0.0f;
-        if (idx_y) idx_y[o] = active ? bcy : 0.0f;
-    }
+    direct_bin(feat, A, out, idx_x, idx_y, n, bin, C, height, width, pooled_width, NB, batch_size, c_begin,
+               min(C, c_begin + cslab));
 }
 
 // con_idx_x / con_idx_y of the reference ABI (kernel.cu:144-145): the bin centre of (roi, ph, pw)

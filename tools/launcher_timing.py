@@ -42,7 +42,19 @@ def bwd():
     assert rc == 1, rc
 
 
-print("RROIAlignForwardLaucher, con_idx NULL      : %.1f us per call" % timed(lambda: fwd(False)))
+nbytes = ext._lib.rroi_align_forward_workspace_bytes(1, 256, 160, 160, 512, 0)
+ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+
+
+def native():
+    rc = ext._lib.rroi_align_forward_hip(F.data_ptr(), 0, 0.25, 1, 512, 160, 160, 256, 8, 64, R.data_ptr(), out.data_ptr(),
+                                         ws.data_ptr(), nbytes, ext.PATH_TILED, st)
+    assert rc == 1, rc
+
+
+for _ in range(2):   # interleaved, same clock: the native entry point (caller's workspace) and the launcher symbol
+    print("rroi_align_forward_hip (native, for scale)  : %.1f us per call" % timed(native, 200, 500))
+    print("RROIAlignForwardLaucher, con_idx NULL      : %.1f us per call" % timed(lambda: fwd(False), 200, 500))
 print("RROIAlignForwardLaucher, con_idx_x/y filled: %.1f us per call" % timed(lambda: fwd(True)))
 print("RROIAlignBackwardLaucher                   : %.1f us per call" % timed(bwd, 10, 50))
 ref = ext.forward(F, R, 8, 64, 0.25)
