@@ -539,15 +539,15 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
                                ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,
                                batch_size, nchunks, ntiles, lay, dt, dp, g_fwd_dbg);
 #ifdef RROI_EXPLORE
-#define RROI_LAUNCH_SPLIT_X(M)                                                                               \
-    hipLaunchKernelGGL((rroi_fwd_split_kernel<true, 2, 2, M>), dim3(sgrid), dim3(2 * kWave), 0, stream, map,   \
-                       ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,     \
+#define RROI_LAUNCH_SPLIT_X(E, O, H)                                                                         \
+    hipLaunchKernelGGL((rroi_fwd_split_kernel<true, 2, E, 1, O, H>), dim3(sgrid), dim3(2 * kWave), 0, stream, \
+                       map, ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size, \
                        nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
-        else if (g_fwd_split == 2) RROI_LAUNCH_SPLIT_X(0);
-        else if (g_fwd_split == 3) RROI_LAUNCH_SPLIT_X(2);
-        else if (g_fwd_split == 4) RROI_LAUNCH_SPLIT_X(3);
-        else if (g_fwd_split == 5) RROI_LAUNCH_SPLIT_X(4);
-        else if (g_fwd_split == 6) RROI_LAUNCH_SPLIT_X(8);
+        else if (g_fwd_split == 2) RROI_LAUNCH_SPLIT_X(0, 6, 3);
+        else if (g_fwd_split == 3) RROI_LAUNCH_SPLIT_X(1, 6, 3);
+        else if (g_fwd_split == 4) RROI_LAUNCH_SPLIT_X(2, 6, 3);
+        else if (g_fwd_split == 5) RROI_LAUNCH_SPLIT_X(2, 5, 3);
+        else if (g_fwd_split == 6) RROI_LAUNCH_SPLIT_X(0, 6, 1);
 #undef RROI_LAUNCH_SPLIT_X
 #endif
         else if ((g_fwd_split || launcher_rest) && g_store_aux == 2 && NB % 4 != 0) RROI_LAUNCH_SPLIT(false);

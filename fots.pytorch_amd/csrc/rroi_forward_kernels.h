@@ -640,7 +640,7 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
 // __syncthreads() nothing here makes the compiler emit s_waitcnt vmcnt(0).
 __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool VEC_STORE, int AUX, int EARLY = 2, int MINOR = 1, int OCC = 5>
+template <bool VEC_STORE, int AUX, int EARLY = 2, int MINOR = 1, int OCC = 5, int HID = 2>
 __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
@@ -967,6 +967,38 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                 }
             }
         }
+        if (HID == 1) {
+            // HI groups one at a time (no second register set: 20 VGPRs fewer)
+#pragma unroll 1
+            for (unsigned it = 0; it < g_hi; ++it) {
+                fetch_hi(p, g_lo + it, 0);
+                issue_hi(rs, 0);
+                blend_hi(0);
+            }
+        } else if (HID == 3) {
+            // two register sets, a ROLLED loop over pairs of groups (the unrolled form costs 28 VGPRs more)
+            if (g_hi > 0) {
+                fetch_hi(p, g_lo, 0);
+                issue_hi(rs, 0);
+#pragma unroll 1
+                for (unsigned it = 0;; it += 2) {
+                    if (it + 1 < g_hi) {
+                        fetch_hi(p, g_lo + it + 1, 1);
+                        issue_hi(rs, 1);
+                        pin_hi(0);
+                    }
+                    blend_hi(0);
+                    if (it + 1 >= g_hi) break;
+                    if (it + 2 < g_hi) {
+                        fetch_hi(p, g_lo + it + 2, 0);
+                        issue_hi(rs, 0);
+                        pin_hi(1);
+                    }
+                    blend_hi(1);
+                    if (it + 2 >= g_hi) break;
+                }
+            }
+        } else
         if (g_hi > 0) {
             fetch_hi(p, g_lo, 0);
             issue_hi(rs, 0);

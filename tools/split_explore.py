@@ -59,7 +59,7 @@ def main():
     torch.cuda.synchronize()
     res = {"split_equals_tiled": bool(torch.equal(top, ref))}
     for rnd in range(rounds):
-        for name, on, wgs in (("tiled", 0, -1), ("split10", 1, 10), ("split9", 1, 9), ("minor0", 2, 10), ("minor2", 3, 10)):
+        for name, on, wgs in (("tiled", 0, -1), ("split10", 1, 10), ("e0o6h3w12", 2, 12), ("e1o6h3w12", 3, 12), ("e2o6h3w12", 4, 12), ("e2o5h3w10", 5, 10), ("e0o6h1w12", 6, 12)):
             lib.rroi_align_debug_set_fwd_split(on, wgs)
             res.setdefault(name + "_step", []).append(timeit(lambda: call(3)))
             res.setdefault(name + "_gather", []).append(timeit(lambda: call(2)))
