@@ -534,7 +534,13 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     hipLaunchKernelGGL((rroi_fwd_split_kernel<VEC, 2>), dim3(sgrid), dim3(2 * kWave), 0, stream, map,     \
                        ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size, \
                        nchunks, ntiles, lay, dt, dp, g_fwd_dbg | (launcher_rest ? 32 : 0))
-        if (out_nhwc)
+        // channels-last crops: the split kernel behind the prologue (55.2 against 56.4-58.6 us at cfg2); with
+        // channels-last features consumed in place the one-wave kernel is as fast or faster (51.6 against 52.3)
+        if (out_nhwc && !zero_copy && g_fwd_split && g_store_aux == 2)
+            hipLaunchKernelGGL((rroi_fwd_split_kernel<true, 2, 2, 1, 5, 2, true>), dim3(sgrid), dim3(2 * kWave), 0, stream,
+                               map, ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,
+                               nchunks, ntiles, lay, dt, dp, g_fwd_dbg);
+        else if (out_nhwc)
             hipLaunchKernelGGL((rroi_fwd_tiled_kernel<true, 2, true>), dim3(grid), dim3(kWave), 0, stream, map,
                                ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,
                                batch_size, nchunks, ntiles, lay, dt, dp, g_fwd_dbg);

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
 // __syncthreads() nothing here makes the compiler emit s_waitcnt vmcnt(0).
 __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool VEC_STORE, int AUX, int EARLY = 2, int MINOR = 1, int OCC = 5, int HID = 2>
+template <bool VEC_STORE, int AUX, int EARLY = 2, int MINOR = 1, int OCC = 5, int HID = 2, bool ONHWC = false>
 __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
@@ -828,6 +828,34 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // phase C, the storer's: the [rows < C] x [64 bins] tile leaves T for its registers between the two
     // barriers, then goes out as 256-byte row segments (dbg & 1, the ablation knob, drops the stores)
     auto drain_tile = [&](unsigned n, unsigned t, unsigned long long cur_mask, bool skip) {
+        if (ONHWC) {
+            // channels-last crops (R, PH*PW, C): lane = (channel quad q, bin b) as in phase B; the tile is read back
+            // along its columns (the mapping put() wrote it with), a store covers 8 bins x 128 B
+            v4f c[kIters];
+#pragma unroll
+            for (int it8 = 0; it8 < kIters; ++it8) {
+                const unsigned bl = (unsigned)it8 * kBinsPerIter + b;   // bin within the tile
+                const float* tr = t_row + (bl ^ wswz);
+                c[it8] = v4f{tr[0], tr[kTStride], tr[2 * kTStride], tr[3 * kTStride]};
+            }
+            wg_lds_barrier();  // T has been read
+            const bool live = !(dbg & 1) && !skip;
+            float* obase = out + (size_t)n * NB * C;
+            const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, (unsigned)NB * (unsigned)C * 4u);
+            const bool q_ok = k * kChunk + q * 4 < (unsigned)C;
+#pragma unroll
+            for (int it8 = 0; it8 < kIters; ++it8) {
+                const unsigned bl = (unsigned)it8 * kBinsPerIter + b;
+                const bool on = (cur_mask >> bl) & 1ull;
+                const v4f o = {on ? c[it8].x : 0.f, on ? c[it8].y : 0.f, on ? c[it8].z : 0.f, on ? c[it8].w : 0.f};
+                const unsigned bin = t * kTileBins + bl;
+                const unsigned off = (bin * (unsigned)C + k * kChunk + q * 4u) * 4u;
+                const unsigned o_off = (live && q_ok && bin < (unsigned)NB) ? off : kOOB;
+                if (AUX == 2 && it8 < MINOR) buf_store<kMinorAux>(ws, o_off, o);
+                else buf_store<AUX>(ws, o_off, o);
+            }
+            return;
+        }
         v4f v[kChunk / 4];
 #pragma unroll
         for (int s4 = 0; s4 < kChunk / 4; ++s4) {
