@@ -175,7 +175,7 @@ def infer_image(net, converter, im, detector=None, segm_thresh=0.5, recognise="b
     """One image through the whole chain of `test.py:75-116`: preprocess -> net -> `get_boxes` on the maps
     where the network wrote them -> RoIRotate + recognition head + greedy CTC for every box ->
     (boxes (n, 9) numpy, texts); like the reference's loop, boxes whose text is empty are dropped
-    (test.py:109-110).
+    (test.py:109-110).  `return_debug` appends (all boxes, the recogniser's (texts, crops, labels), the features).
 
     `detector`: optional hook `im_data -> (score (h, w), rbox (4, h, w), angle (2, h, w))` device tensors
     that stand in for the three head outputs -- random weights pass no box (or a hundred thousand)
@@ -203,4 +203,4 @@ def infer_image(net, converter, im, detector=None, segm_thresh=0.5, recognise="b
     texts = out[0] if return_debug else out
     keep = [i for i, t in enumerate(texts) if len(t) > 0]
     res = (boxes[keep], [texts[i] for i in keep])
-    return res + ((boxes, out),) if return_debug else res
+    return res + ((boxes, out, feats),) if return_debug else res
