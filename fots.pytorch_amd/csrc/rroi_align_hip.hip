@@ -204,6 +204,11 @@ struct BwdWorkspace {
     size_t gcm_bytes, cnt_bytes;
     size_t bytes;
     bool gather_ok;  // the gather formulation's 32-bit indices hold for this problem
+    // one-pass lists (round 3): per-pixel buckets of 1 << kshift pairs in `pairs`, the overflow array behind
+    // them, the chains' heads in `off`, the overflow counter in `bsum`
+    bool bucket_ok, bucket_pref;
+    unsigned kshift;
+    uint4* ov;
 };
 
 BwdWorkspace carve_bwd(void* ws, int batch_size, int channels, int height, int width, int num_rois, int NB)
@@ -221,7 +226,16 @@ BwdWorkspace carve_bwd(void* ws, int batch_size, int channels, int height, int w
     w.cnt_bytes = align_up(nkeys * sizeof(int), 256);
     const size_t off_bytes = align_up((nkeys + 1) * sizeof(unsigned), 256);
     const size_t bsum_bytes = align_up((size_t)w.scan_blocks * sizeof(unsigned), 256);
-    const size_t pair_bytes = align_up(4 * R * NB * sizeof(uint2), 256);
+    // bucket capacity: ~3x the average list (about 2 pairs per bin over the map's pixels), a power of two in
+    // [16, 128]; a denser problem keeps the exact count / scan / fill lists
+    const double avg = 2.0 * (double)R * NB / ((double)batch_size * height * width);
+    w.kshift = 4;
+    while ((1u << w.kshift) < 3.0 * avg && w.kshift < 7) ++w.kshift;
+    w.bucket_pref = avg <= 192.0;   // denser: most of a list would live in the (slow) chains
+    w.bucket_ok = (nkeys << w.kshift) < (1ull << 32) && 4 * R * NB < (1ull << 31);
+    const size_t bucket_bytes = w.bucket_ok ? align_up((nkeys << w.kshift) * sizeof(uint2), 256) : 0;
+    const size_t ov_bytes = w.bucket_ok ? align_up(4 * R * NB * sizeof(uint4), 256) : 0;
+    const size_t pair_bytes = std::max(align_up(4 * R * NB * sizeof(uint2), 256), bucket_bytes + ov_bytes);
     const size_t td_bytes = align_up(R * (size_t)NB * nchunks * kLineBytes, 256);   // (R, NB, nchunks * 32)
     // pair slots, top_diff line indices and keys are 32-bit; the gather launches one thread group per key
     // ... and its thread index (key * lanes-per-pixel, at most 64) and block index are 32-bit too
@@ -239,6 +253,7 @@ BwdWorkspace carve_bwd(void* ws, int batch_size, int channels, int height, int w
     w.bsum = reinterpret_cast<unsigned*>(b);
     b += bsum_bytes;
     w.pairs = reinterpret_cast<uint2*>(b);
+    w.ov = reinterpret_cast<uint4*>(b + bucket_bytes);
     b += pair_bytes;
     w.tdT = reinterpret_cast<float*>(b);
     b += td_bytes;
@@ -281,6 +296,7 @@ int g_prologue_aux = 0;
 // write-through leaves no dirty lines for the end of the launch to flush.  (Round 1, with two more
 // launches in the call, had nt ahead by 2 us.)  Non-temporal LOADS in the gather: +16 us.
 int g_bwd_relayout_aux = 16;
+int g_bwd_buckets = 1;  // one-pass pixel lists (round 3); 0: count / scan / fill as in rounds 1-2
 
 
 // ------------------------------------------------------------------------------------
@@ -611,6 +627,12 @@ int rroi_align_debug_set_fwd_split(int on, int wgs_per_cu)
     if (wgs_per_cu > 0) g_split_wgs_per_cu = wgs_per_cu;
     return old;
 }
+int rroi_align_debug_set_bwd_buckets(int v)
+{
+    const int old = g_bwd_buckets;
+    g_bwd_buckets = v;
+    return old;
+}
 int rroi_align_debug_set_fwd_dbg(int v)
 {
     const int old = g_fwd_dbg;
@@ -684,6 +706,12 @@ int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, i
 }
 
 // accumulate (the reference-ABI launcher, tiled NCHW paths only): bottom_diff += gradient instead of = gradient
+// AUTO / TILED choose among the gathers; LISTS and INKERNEL name one
+static inline bool gather_choice_is_open(int path)
+{
+    return path != RROI_PATH_TILED_LISTS && path != RROI_PATH_TILED_INKERNEL;
+}
+
 static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_diff_layout,
                          float spatial_scale, int batch_size, int num_rois, int height, int width, int channels,
                          int pooled_height, int pooled_width, const float* rois, float* bottom_diff,
@@ -700,7 +728,8 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
     if (!shape_ok(batch_size, num_rois, height, width, channels, pooled_height, pooled_width))
         return 0;
     if (path != RROI_PATH_AUTO && path != RROI_PATH_DIRECT && path != RROI_PATH_TILED &&
-        path != RROI_PATH_TILED_ATOMIC && path != RROI_PATH_TILED_LISTS && path != RROI_PATH_TILED_INKERNEL)
+        path != RROI_PATH_TILED_ATOMIC && path != RROI_PATH_TILED_LISTS && path != RROI_PATH_TILED_INKERNEL &&
+        path != RROI_PATH_TILED_BUCKETS)
         return 0;
     if (!bottom_diff) return 0;
     const int NB = pooled_height * pooled_width;
@@ -752,8 +781,18 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
     // pixel -- C = 256, 160 x 160, 8 x 64: R = 4 45.9 / 52.8, 16 49.5 / 52.5, 32 49.7 / 53.7, 64 56.9 / 57.4, 128 78.3 / 65.5
     const bool very_short = (double)num_rois * NB <= 1.0 * (double)batch_size * HW;
     const bool prefer_inkernel = scan_ok && (nchunks <= 2 || (nchunks <= 4 && short_lists) || (nchunks <= 8 && very_short));
-    const bool lists = path == RROI_PATH_TILED_LISTS || !inkernel_ok ||
+    if (path == RROI_PATH_TILED_BUCKETS && !(gather && ws.bucket_ok)) return 0;
+    // Round 3: the lists in HBM built in ONE pass over the bins (fixed buckets of 2^kshift entries per pixel plus
+    // overflow chains, rroi_backward_kernels.h) instead of count / scan / fill.  Measured (tools/crossover.py,
+    // tools/bucket_ab.py, profiles/r03_crossover_buckets.txt; us per call, buckets / exact lists / K3t): cfg3 129 /
+    // 144 / 179;  C = 256 R = 16 37 / 53 / 48;  C = 64 176x320 R = 128 40 / 48 / 43;  8 images of 160x160 R = 64
+    // 49 / 61 / 61 -- they win everywhere up to ~128 list entries per map pixel (74 / 89 / 164 there) and lose
+    // beyond (512 per pixel: 200 / 128 / 318), where most of a list lives in the chains: bucket_pref.
+    const bool buckets = gather && ws.bucket_ok && gather_choice_is_open(path) &&
+                         (path == RROI_PATH_TILED_BUCKETS || (ws.bucket_pref && g_bwd_buckets));
+    const bool lists = buckets || path == RROI_PATH_TILED_LISTS || !inkernel_ok ||
                        (path != RROI_PATH_TILED_INKERNEL && !prefer_inkernel);
+    const BucketLists BL = {ws.kshift, reinterpret_cast<int*>(ws.off), ws.bsum, ws.ov};
     {
         // affine table; the list passes' pixel counters (K3g) are cleared by the same launch
         const unsigned nzero = gather && lists ? ws.keys.keys : 0u;
@@ -761,7 +800,8 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
         const int zblocks = nzero ? (int)std::min<long>(ceil_div((long)nzero, 1024), 2L * num_cus()) : 0;
         if (zblocks > ablocks) ablocks = zblocks;
         hipLaunchKernelGGL(rroi_affine_kernel, dim3(ablocks), dim3(256), 0, stream, rois, num_rois, pooled_height,
-                           spatial_scale, ws.aff, ws.cnt, nzero);
+                           spatial_scale, ws.aff, ws.cnt, nzero, buckets ? BL.head : (int*)nullptr,
+                           buckets ? BL.ovcnt : (unsigned*)nullptr);
     }
     int st = launch_status();
     if (st != 1) return st;
@@ -785,7 +825,7 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
             const long cap = (long)num_cus() * 8;
             if (blocks > cap) blocks = cap;
 #define RROI_LAUNCH_R(SAUX)                                                                              \
-    hipLaunchKernelGGL((rroi_bwd_pairs_relayout_kernel<false, SAUX>), dim3((unsigned)blocks), dim3(256), 0,   \
+    hipLaunchKernelGGL((rroi_bwd_pairs_relayout_kernel<0, SAUX>), dim3((unsigned)blocks), dim3(256), 0,       \
                        stream, ws.aff, num_rois, height, width, pooled_width, NB, batch_size, lines_per_roi, \
                        dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs, 0, top_diff, ws.tdT, channels,       \
                        nchunks, tt, (int)blocks, 0, (int)tiles, ws.scan_blocks, 0)
@@ -857,21 +897,29 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
                        dim3(256), 0, stream, ws.aff, num_rois, height, width, pooled_width, NB,          \
                        batch_size, lines_per_roi, dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs,       \
                        pblocks, top_diff, ws.tdT, channels, nchunks, tt, (int)(BLOCKS), (int)(T0), (int)(T1),            \
-                       ws.scan_blocks, raw_bsum)
+                       ws.scan_blocks, raw_bsum, BL)
+        if (buckets) {
+            // ONE launch: every pair into its pixel's bucket (or overflow chain) || the whole relayout
+            const long blocks = relayout_grid(tiles);
+            if (g_bwd_relayout_aux == 16) RROI_LAUNCH_PR(2, 16, blocks, 0, tiles);
+            else if (g_bwd_relayout_aux == 2) RROI_LAUNCH_PR(2, 2, blocks, 0, tiles);
+            else RROI_LAUNCH_PR(2, 0, blocks, 0, tiles);
+        } else {
         {
             const long blocks = relayout_grid(half);
-            if (g_bwd_relayout_aux == 16) RROI_LAUNCH_PR(false, 16, blocks, 0, half);
-            else if (g_bwd_relayout_aux == 2) RROI_LAUNCH_PR(false, 2, blocks, 0, half);
-            else RROI_LAUNCH_PR(false, 0, blocks, 0, half);
+            if (g_bwd_relayout_aux == 16) RROI_LAUNCH_PR(0, 16, blocks, 0, half);
+            else if (g_bwd_relayout_aux == 2) RROI_LAUNCH_PR(0, 2, blocks, 0, half);
+            else RROI_LAUNCH_PR(0, 0, blocks, 0, half);
         }
         hipLaunchKernelGGL(rroi_scan1_kernel, dim3(ws.scan_blocks), dim3(1024), 0, stream, ws.cnt, ws.off,
                            ws.bsum, KL.keys);
         if (!raw_bsum) hipLaunchKernelGGL(rroi_scan2_kernel, dim3(1), dim3(1024), 0, stream, ws.bsum, ws.scan_blocks);
         {
             const long blocks = relayout_grid(tiles - half);
-            if (g_bwd_relayout_aux == 16) RROI_LAUNCH_PR(true, 16, blocks, half, tiles);
-            else if (g_bwd_relayout_aux == 2) RROI_LAUNCH_PR(true, 2, blocks, half, tiles);
-            else RROI_LAUNCH_PR(true, 0, blocks, half, tiles);
+            if (g_bwd_relayout_aux == 16) RROI_LAUNCH_PR(1, 16, blocks, half, tiles);
+            else if (g_bwd_relayout_aux == 2) RROI_LAUNCH_PR(1, 2, blocks, half, tiles);
+            else RROI_LAUNCH_PR(1, 0, blocks, half, tiles);
+        }
         }
 #undef RROI_LAUNCH_PR
         st = launch_status();
@@ -883,17 +931,21 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
         // whole groups of 8 key tiles (the kernel deals the tiles of a group to the 8 XCDs)
         const long wg_per_tile = 32 / groups_per_block;  // 1, 2, 4 or 8
         const long gblocks = ceil_div(ceil_div((long)KL.keys, 32L), 8L) * 8L * wg_per_tile;
+        // the lists: count / scan / fill segments (`off` = scanned offsets) or buckets (`off` = the counters)
+        const unsigned* loff = buckets ? reinterpret_cast<const unsigned*>(ws.cnt) : ws.off;
+#define RROI_LAUNCH_G(NHWC, BUCK, DST)                                                                        \
+    hipLaunchKernelGGL((rroi_bwd_gather_kernel<NHWC, BUCK>), dim3((unsigned)gblocks), dim3(256), 0, stream,    \
+                       td_nhwc ? top_diff : ws.tdT, loff, ws.bsum, ws.pairs, DST, channels, height, width,    \
+                       pitch, nchunks, chunk_stride, line_stride, sub_shift, KL, make_fastdiv(KL.Ht * KL.Wt), \
+                       make_fastdiv(KL.Wt), ws.scan_blocks, raw_bsum, BL)
         if (bd_nhwc) {
-            hipLaunchKernelGGL(rroi_bwd_gather_kernel<true>, dim3((unsigned)gblocks), dim3(256), 0, stream,
-                               td_nhwc ? top_diff : ws.tdT, ws.off, ws.bsum, ws.pairs, bottom_diff, channels,
-                               height, width, pitch, nchunks, chunk_stride, line_stride, sub_shift, KL,
-                               make_fastdiv(KL.Ht * KL.Wt), make_fastdiv(KL.Wt), ws.scan_blocks, raw_bsum);
+            if (buckets) RROI_LAUNCH_G(true, true, bottom_diff);
+            else RROI_LAUNCH_G(true, false, bottom_diff);
             return launch_status();  // written in place: no relayout back
         }
-        hipLaunchKernelGGL(rroi_bwd_gather_kernel<false>, dim3((unsigned)gblocks), dim3(256), 0, stream,
-                           td_nhwc ? top_diff : ws.tdT, ws.off, ws.bsum, ws.pairs, ws.gcm, channels, height,
-                           width, pitch, nchunks, chunk_stride, line_stride, sub_shift, KL,
-                           make_fastdiv(KL.Ht * KL.Wt), make_fastdiv(KL.Wt), ws.scan_blocks, raw_bsum);
+        if (buckets) RROI_LAUNCH_G(false, true, ws.gcm);
+        else RROI_LAUNCH_G(false, false, ws.gcm);
+#undef RROI_LAUNCH_G
         st = launch_status();
         if (st != 1) return st;
     } else {

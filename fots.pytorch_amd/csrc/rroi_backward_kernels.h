@@ -106,16 +106,28 @@ struct PatchMap {
     unsigned pc_shift;      // log2(columns of a patch); rows of a patch = 64 >> pc_shift
 };
 
-// FILL == false: cnt[key] += 1 per pair.  FILL == true: cnt counts back down, handing out the
-// slots of the key's segment.
-template <bool FILL>
+// The overflow side of the bucket lists (MODE 2): a pair that finds its pixel's bucket full goes into one
+// global array, chained per pixel (head[key] -> entry -> entry.next ...).
+struct BucketLists {
+    unsigned kshift;              // bucket of key k: pairs[k << kshift .. ), capacity 1 << kshift
+    int* head;                    // per key: index of the newest overflow entry, -1 = none
+    unsigned* ovcnt;              // entries handed out so far
+    uint4* ov;                    // {bin line, weight bits, next, -}; room for every pair of the problem
+};
+
+// MODE 0: cnt[key] += 1 per pair (count pass).  MODE 1: cnt counts back down, handing out the slots of
+// the key's segment (fill pass, after the scan).  MODE 2 (round 3): ONE pass -- cnt[key]++ hands out the
+// slots of a fixed-capacity bucket per pixel (a few times the average list), the rare pair beyond it is
+// chained into the overflow array: no count pass, no scan, and the relayout of top_diff is one launch.
+template <int MODE>
 __device__ __forceinline__ void pairs_body(unsigned idx, const Affine* __restrict__ aff, int num_rois,
                                            int height, int width, int pooled_height, int pooled_width, int batch_size,
                                            unsigned lines_per_roi, const PatchMap& pm,
                                            const KeyLayout& L, int* __restrict__ cnt,
                                            const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
-                                           uint2* __restrict__ pairs)
+                                           uint2* __restrict__ pairs, const BucketLists& bl)
 {
+    constexpr bool FILL = MODE == 1;
     const unsigned n = fdiv(idx, pm.div_roi);
     if (n >= (unsigned)num_rois) return;
     const unsigned rem = idx - n * pm.lanes_per_roi;
@@ -127,7 +139,17 @@ __device__ __forceinline__ void pairs_body(unsigned idx, const Affine* __restric
     const unsigned j = ph * (unsigned)pooled_width + pw;
     const Affine A = aff[n];
     bin_pairs(A, ph, pw, height, width, batch_size, L, [&](unsigned key, float w) {
-        if (!FILL) {
+        if (MODE == 2) {
+            const unsigned slot = (unsigned)atomicAdd(cnt + key, 1);
+            const uint2 rec = make_uint2(n * lines_per_roi + j, as_u(w));
+            if (slot < (1u << bl.kshift)) {
+                pairs[((size_t)key << bl.kshift) + slot] = rec;
+            } else {
+                const unsigned e = atomicAdd(bl.ovcnt, 1u);
+                const int prev = atomicExch(bl.head + key, (int)e);
+                bl.ov[e] = make_uint4(rec.x, rec.y, (unsigned)prev, 0u);
+            }
+        } else if (!FILL) {
             atomicAdd(cnt + key, 1);
         } else {
             const int slot = atomicAdd(cnt + key, -1) - 1;
@@ -141,22 +163,22 @@ __device__ __forceinline__ void pairs_body(unsigned idx, const Affine* __restric
 // the pair lists -- bound by the atomic request rate -- and the rest relay out tiles
 // [tile_begin, tile_end) of top_diff -- bound by HBM.  They share the chip instead of running
 // one after the other; the host gives each of the two launches half of the tiles.
-template <bool FILL, int SAUX>
+template <int MODE, int SAUX>
 __global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
     const Affine* __restrict__ aff, int num_rois, int height, int width, int pooled_width, int NB,
     int batch_size, unsigned lines_per_roi, PatchMap pm, FastDiv div_pw, KeyLayout L,
     int* __restrict__ cnt, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
     uint2* __restrict__ pairs, int pair_blocks, const float* __restrict__ top_diff,
     float* __restrict__ tdT, int C, int nchunks, int ptiles, int relayout_blocks, int tile_begin,
-    int tile_end, unsigned scan_blocks, int raw_bsum)
+    int tile_end, unsigned scan_blocks, int raw_bsum, BucketLists bl = BucketLists{0u, nullptr, nullptr, nullptr})
 {
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
     if ((int)blockIdx.x < pair_blocks) {
-        if (FILL) bsum = block_prefix(bsum, scan_blocks, raw_bsum != 0, reinterpret_cast<unsigned*>(T));
+        if (MODE == 1) bsum = block_prefix(bsum, scan_blocks, raw_bsum != 0, reinterpret_cast<unsigned*>(T));
         const unsigned total = (unsigned)num_rois * pm.lanes_per_roi;
         for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += (unsigned)pair_blocks * 256u)
-            pairs_body<FILL>(idx, aff, num_rois, height, width, NB / pooled_width, pooled_width, batch_size,
-                             lines_per_roi, pm, L, cnt, off, bsum, pairs);
+            pairs_body<MODE>(idx, aff, num_rois, height, width, NB / pooled_width, pooled_width, batch_size,
+                             lines_per_roi, pm, L, cnt, off, bsum, pairs, bl);
         return;
     }
     // block j takes the pixel ranges j, j + blocks, ... of [tile_begin, tile_end), all chunks of each
@@ -230,15 +252,18 @@ __global__ __launch_bounds__(1024) void rroi_scan2_kernel(unsigned* __restrict__
 // gather: `sub` = 8 * nchunks_pass lanes serve one pixel (lane -> chunk, channel quad); 64 / sub
 // pixels per wave; one pixel group per thread group, so the hardware's block dispatch balances
 // the (very uneven) list lengths.  The 16-byte loads of eight pairs are in flight together.
-template <bool DST_NHWC>
+// BUCKET: the lists are the fixed-capacity buckets of the one-pass build (`off` = the per-key counters, `bsum`
+// unused) plus the per-key overflow chains.
+template <bool DST_NHWC, bool BUCKET = false>
 __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     const float* __restrict__ tdT, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
     const uint2* __restrict__ pairs, float* __restrict__ gcm, int C, int height, int width, int pitch,
     int nchunks, unsigned chunk_stride, unsigned line_stride, unsigned sub_shift, KeyLayout L,
-    FastDiv div_bt, FastDiv div_wt, unsigned scan_blocks, int raw_bsum)
+    FastDiv div_bt, FastDiv div_wt, unsigned scan_blocks, int raw_bsum,
+    BucketLists bl = BucketLists{0u, nullptr, nullptr, nullptr})
 {
     __shared__ unsigned bs_lds[kInlineScanBlocks];
-    bsum = block_prefix(bsum, scan_blocks, raw_bsum != 0, bs_lds);  // before any thread leaves
+    if (!BUCKET) bsum = block_prefix(bsum, scan_blocks, raw_bsum != 0, bs_lds);  // before any thread leaves
     // Workgroup -> keys: the G = 2^(sub_shift-3) workgroups that cover one 8 x 4 key tile get
     // block indices that are equal modulo 8, i.e. run on ONE XCD: neighbouring pixels share
     // source lines (the 2 x 2 footprint of a bin), and only an XCD's own L2 can serve them twice.
@@ -258,7 +283,17 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     const unsigned by = fdiv(r, div_wt);
     const unsigned y = by * 4u + (in >> 3), x = (r - by * L.Wt) * 8u + (in & 7u);
     if (y >= (unsigned)height || x >= (unsigned)width) return;  // padding of the key space
-    const unsigned beg = list_offset(off, bsum, key), end = list_offset(off, bsum, key + 1u);
+    unsigned beg, end;
+    int chain = -1;   // BUCKET: newest overflow entry of this pixel
+    if (BUCKET) {
+        const unsigned have = off[key];
+        beg = key << bl.kshift;
+        end = beg + min(have, 1u << bl.kshift);
+        if (have > (1u << bl.kshift)) chain = bl.head[key];
+    } else {
+        beg = list_offset(off, bsum, key);
+        end = list_offset(off, bsum, key + 1u);
+    }
     const unsigned quad = sl & 7u;
     const unsigned slice_px = (unsigned)height * (unsigned)pitch;
     const v4f z4 = {0.f, 0.f, 0.f, 0.f};
@@ -317,6 +352,24 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
                             }
                         }
                     }
+                }
+            }
+            if (BUCKET) {
+                // the pixel's overflow chain (rare: a list longer than the bucket), one entry at a time
+                for (int e = chain; e >= 0;) {
+                    const uint4 rec = bl.ov[e];
+                    const v4f g = c_ok ? *reinterpret_cast<const v4f*>(src + (size_t)rec.x * line_stride) : z4;
+                    const float w = as_f(rec.y & 0x7fffffffu);
+                    if (EXACT) {
+                        acc += g * w;
+                        if (rec.y & 0x80000000u) acc += g * 0.0f;
+                    } else {
+                        acc.x = __builtin_fmaf(g.x, w, acc.x);
+                        acc.y = __builtin_fmaf(g.y, w, acc.y);
+                        acc.z = __builtin_fmaf(g.z, w, acc.z);
+                        acc.w = __builtin_fmaf(g.w, w, acc.w);
+                    }
+                    e = (int)rec.z;
                 }
             }
             return acc;

@@ -236,12 +236,18 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
 
 // per-ROI affine table; the backward also has it clear its pixel counters (`zero`, `nzero` ints)
 // instead of paying a memset launch of their own
+// (bucket lists, round 3: also the overflow chains' heads = -1 and the overflow counter = 0)
 __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois, int pooled_height,
                                    float spatial_scale, Affine* __restrict__ aff, int* __restrict__ zero = nullptr,
-                                   unsigned nzero = 0)
+                                   unsigned nzero = 0, int* __restrict__ heads = nullptr,
+                                   unsigned* __restrict__ counter = nullptr)
 {
     const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
-    for (unsigned j = gid; j < nzero; j += gridDim.x * blockDim.x) zero[j] = 0;
+    for (unsigned j = gid; j < nzero; j += gridDim.x * blockDim.x) {
+        zero[j] = 0;
+        if (heads) heads[j] = -1;
+    }
+    if (counter && gid == 0) *counter = 0u;
     if (gid < (unsigned)num_rois) aff[gid] = make_affine(rois + (size_t)gid * 6, pooled_height, spatial_scale);
 }
 

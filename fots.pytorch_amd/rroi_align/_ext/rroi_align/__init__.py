@@ -22,6 +22,10 @@ LIB_PATH = os.path.join(_HERE, "librroi_align_hip.so")
 
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 PATH_AUTO, PATH_DIRECT, PATH_TILED, PATH_TILED_ATOMIC, PATH_TILED_LISTS, PATH_TILED_INKERNEL = 0, 1, 2, 3, 4, 5
+PATH_TILED_BUCKETS = 6  # backward only: the gather over pixel lists built in one pass (buckets + overflow chains)
+# the gather formulations of the backward (they also read / write channels-last tensors in place), and every path
+GATHER_PATHS = (PATH_TILED, PATH_TILED_LISTS, PATH_TILED_BUCKETS, PATH_TILED_INKERNEL)
+BACKWARD_PATHS = (PATH_AUTO, PATH_DIRECT, PATH_TILED_ATOMIC) + GATHER_PATHS
 STAGE_PROLOGUE, STAGE_GATHER, STAGE_ALL = 1, 2, 3
 # every value `path` may take in forward() (the parity tests run them all)
 FORWARD_PATHS = (PATH_AUTO, PATH_DIRECT, PATH_TILED)
@@ -210,12 +214,12 @@ def backward(grad_output: torch.Tensor, rois: torch.Tensor, feature_size, spatia
     # the 256 MiB, no relayout pass
     layout = LAYOUT_NCHW
     if (not grad_output.is_contiguous() and grad_output.is_contiguous(memory_format=torch.channels_last)
-            and C % 4 == 0 and path in (PATH_AUTO, PATH_TILED, PATH_TILED_LISTS, PATH_TILED_INKERNEL) and R > 0):
+            and C % 4 == 0 and path in (PATH_AUTO,) + GATHER_PATHS and R > 0):
         layout = LAYOUT_NHWC
     else:
         grad_output = grad_output.contiguous()
     rois = rois.contiguous()
-    cl_grad = bool(channels_last_grad) and C % 4 == 0 and path in (PATH_AUTO, PATH_TILED, PATH_TILED_LISTS, PATH_TILED_INKERNEL) and R > 0
+    cl_grad = bool(channels_last_grad) and C % 4 == 0 and path in (PATH_AUTO,) + GATHER_PATHS and R > 0
     with torch.cuda.device_of(grad_output):
         grad_in = torch.empty((B, C, H, W), dtype=torch.float32, device=grad_output.device,
                               memory_format=torch.channels_last if cl_grad else torch.contiguous_format)

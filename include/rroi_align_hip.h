@@ -79,6 +79,10 @@ int rroi_align_release_launcher_scratch(void);
 #define RROI_PATH_TILED_LISTS 4  /* backward only: the gather over per-pixel lists built in HBM by
                                     count / scan / fill launches (what TILED runs for C > 128,
                                     and for C > 64 when the lists are long)                  */
+#define RROI_PATH_TILED_BUCKETS 6 /* backward only (round 3): the gather over per-pixel lists built in ONE pass --
+                                    fixed-capacity buckets per pixel plus overflow chains: no count pass, no
+                                    scan (what TILED runs where TILED_LISTS used to, while the average list
+                                    is short enough for buckets)                                           */
 #define RROI_PATH_TILED_INKERNEL 5 /* backward only: the gather that finds each map tile's bins
                                     inside the kernel (what TILED runs for C <= 64, and for C <= 128
                                     while there are at most 8 bins per map pixel)            */

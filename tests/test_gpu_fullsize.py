@@ -73,7 +73,7 @@ def test_cfg3_forward_backward(ext, oracle, full):
     g2 = ext.backward(pooled.detach() * 4, rois, f.shape, 0.25)
     assert torch.allclose(g2, 2 * g1, rtol=1e-4, atol=1e-4 * scale)
     # direct, both gathers (lists in HBM / lists built in the kernel) and the atomic scatter agree
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
         gd = ext.backward(pooled.detach() * 2, rois, f.shape, 0.25, path=p)
         assert (gd - g1).abs().max().item() <= 1e-4 * scale
 

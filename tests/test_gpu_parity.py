@@ -118,7 +118,7 @@ def test_golden_fixtures(ext, name):
     geom = ext.bin_centres(dev(z["rois"]), ph, pw, s, H, W).cpu().numpy()
     assert eq(geom, z["geom"])
     gout = (2.0 * np.nan_to_num(z["out"])).astype(np.float32)
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
         gin = ext.backward(dev(gout), dev(z["rois"]), z["features"].shape, s, path=p).cpu().numpy()
         scale = max(1.0, float(np.abs(z["grad_in"]).max()))
         assert np.abs(gin - z["grad_in"]).max() <= BWD_RTOL * scale
@@ -147,7 +147,8 @@ def test_backward_vs_oracle(ext, oracle, name, path):
     gout = (2 * out).astype(np.float32)
     want = oracle.backward_c(gout, r, f.shape, s)
     p = {"direct": ext.PATH_DIRECT, "tiled": ext.PATH_TILED, "tiled_lists": ext.PATH_TILED_LISTS,
-         "tiled_inkernel": ext.PATH_TILED_INKERNEL, "tiled_atomic": ext.PATH_TILED_ATOMIC}[path]
+         "tiled_inkernel": ext.PATH_TILED_INKERNEL, "tiled_atomic": ext.PATH_TILED_ATOMIC,
+         "tiled_buckets": ext.PATH_TILED_BUCKETS}[path]
     got = ext.backward(dev(gout), dev(r), f.shape, s, path=p).cpu().numpy()
     scale = max(1.0, float(np.abs(want).max()))
     assert np.abs(got - want).max() <= BWD_RTOL * scale
@@ -160,7 +161,7 @@ def test_backward_edge_rois(ext, oracle):
     rois = np.concatenate([Wk.edge_rois(), Wk.degenerate_rois()[[0, 1, 2, 3, 4]]])
     gout = rng.standard_normal((len(rois), 8, 8, 64), dtype=np.float32)
     want = oracle.backward_c(gout, rois, f.shape, 0.25)
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
         got = ext.backward(dev(gout), dev(rois), f.shape, 0.25, path=p).cpu().numpy()
         assert np.abs(got - want).max() <= BWD_RTOL * max(1.0, float(np.abs(want).max()))
 
@@ -182,7 +183,7 @@ def test_backward_heavy_overlap(ext, oracle):
         rois[: R // 3] = rois[0]                      # identical copies
         gout = rng.standard_normal((R, C, ph, pw), dtype=np.float32)
         want = oracle.backward_c(gout, rois, f.shape, 0.25)
-        for p in (ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
+        for p in (ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
             got = ext.backward(dev(gout), dev(rois), f.shape, 0.25, path=p).cpu().numpy()
             assert np.abs(got - want).max() <= BWD_RTOL * max(1.0, float(np.abs(want).max())), (R, p)
 
@@ -196,7 +197,7 @@ def test_more_than_256_channels(ext, oracle):
         assert mismatch(run_fwd(ext, f, r, 8, 32, 0.25, p), want)[0] == 0
     gout = np.random.default_rng(41).standard_normal(want.shape).astype(np.float32)
     gwant = oracle.backward_c(gout, r, f.shape, 0.25)
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
         g = ext.backward(dev(gout), dev(r), f.shape, 0.25, path=p).cpu().numpy()
         assert np.abs(g - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max())), f"path {p}"
 
@@ -208,7 +209,7 @@ def test_backward_many_rois_on_one_pixel(ext, oracle):
     r = np.repeat(r, 200, axis=0)
     gout = np.random.default_rng(43).standard_normal((200, 16, 8, 64)).astype(np.float32)
     gwant = oracle.backward_c(gout, r, f.shape, 0.25)
-    for p in (ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
+    for p in (ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
         g = ext.backward(dev(gout), dev(r), f.shape, 0.25, path=p).cpu().numpy()
         assert np.abs(g - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max()))
         assert np.array_equal(g == 0, gwant == 0)
@@ -289,7 +290,7 @@ def test_channels_last_pipeline_through_autograd(ext, oracle):
     gout = (2 * want).astype(np.float32)
     for G in (dev(gout), dev(gout).contiguous(memory_format=torch.channels_last)):
         for cl in (False, True):
-            for p in (ext.PATH_AUTO, ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL):
+            for p in (ext.PATH_AUTO, ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL):
                 g = ext.backward(G, dev(r), f.shape, s, path=p, channels_last_grad=cl)
                 assert g.is_contiguous(memory_format=torch.channels_last) == cl or g.is_contiguous()
                 assert np.abs(g.cpu().numpy() - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max()))
@@ -303,7 +304,7 @@ def test_backward_channels_last_grad(ext, oracle, name):
     want = oracle.backward_c(gout, r, f.shape, s)
     G = dev(gout).contiguous(memory_format=torch.channels_last)
     assert not G.is_contiguous()
-    for p in (ext.PATH_AUTO, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL):
+    for p in (ext.PATH_AUTO, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL):
         got = ext.backward(G, dev(r), f.shape, s, path=p).cpu().numpy()
         assert np.abs(got - want).max() <= BWD_RTOL * max(1.0, float(np.abs(want).max()))
     # paths that need NCHW fall back to a contiguous copy
@@ -334,7 +335,7 @@ def test_backward_nonfinite_gradients(ext, oracle):
     want = oracle.backward_c(gout, r, f.shape, 0.25)
     assert np.isnan(want).any()
     fin = np.isfinite(want)
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
         got = ext.backward(dev(gout), dev(r), f.shape, 0.25, path=p).cpu().numpy()
         assert np.array_equal(np.isnan(got), np.isnan(want)), f"path {p}"
         assert np.array_equal(np.isposinf(got), np.isposinf(want)) and np.array_equal(np.isneginf(got), np.isneginf(want))
@@ -550,7 +551,7 @@ def test_random_shape_sweep(ext, oracle):
             assert n == 0, f"trial {trial} C={C} {H}x{W} B={B} {ph}x{pw} s={s} R={R} path={p}: {n} differ (max {d})"
         gout = np.random.default_rng(trial).standard_normal(want.shape).astype(np.float32)
         gwant = oracle.backward_c(gout, r, f.shape, s)
-        for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
+        for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
             g = ext.backward(dev(gout), dev(r), f.shape, s, path=p).cpu().numpy()
             assert np.abs(g - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max())), f"trial {trial} bwd path={p}"
 

@@ -69,8 +69,7 @@ def test_backward_paths_reproduce_the_reference_gradient(name):
     gout = torch.from_numpy((2 * np.nan_to_num(z["out"])).astype(np.float32)).cuda()
     want = z["grad_in"]
     scale = max(1.0, float(np.abs(want).max()))
-    for path in (ext.PATH_AUTO, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL,
-                 ext.PATH_TILED_ATOMIC, ext.PATH_DIRECT):
+    for path in ext.BACKWARD_PATHS:
         got = ext.backward(gout, R, z["features"].shape, s, path=path).cpu().numpy()
         assert np.abs(got - want).max() <= 1e-4 * scale, (name, path)
         assert np.array_equal(got == 0, want == 0), f"{name} path {path}: support of the gradient differs"

@@ -88,7 +88,7 @@ def test_backward_matches_reference_kernel(ref):
                                  want.data_ptr(), ix.data_ptr(), iy.data_ptr(),
                                  torch.cuda.current_stream().cuda_stream)
     scale = float(want.abs().max())
-    for path in (ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC, ext.PATH_DIRECT):
+    for path in (ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC, ext.PATH_DIRECT):
         got = ext.backward(gout, R, f.shape, 0.25, path=path)
         assert float((got - want).abs().max()) <= 1e-4 * scale
 

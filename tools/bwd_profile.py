@@ -33,7 +33,10 @@ if os.environ.get("RROI_BWD_ONLY"):   # the default path alone (for counter pass
         call(ext.PATH_TILED)
     torch.cuda.synchronize()
     sys.exit(0)
-for name, path, n in (("tiled (default: lists in HBM for C > 64)", ext.PATH_TILED, 50), ("tiled_inkernel (lists built in the gather kernel)", ext.PATH_TILED_INKERNEL, 50),
+for name, path, n in (("tiled (default: lists in HBM for C > 64)", ext.PATH_TILED, 50),
+                      ("tiled_lists (count / scan / fill)", ext.PATH_TILED_LISTS, 50),
+                      ("tiled_buckets (one-pass buckets + overflow chains)", ext.PATH_TILED_BUCKETS, 50),
+                      ("tiled_inkernel (lists built in the gather kernel)", ext.PATH_TILED_INKERNEL, 50),
                       ("tiled_atomic (scatter)", ext.PATH_TILED_ATOMIC, 20),
                       ("direct", ext.PATH_DIRECT, 5)):
     for _ in range(3):

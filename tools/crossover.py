@@ -26,5 +26,6 @@ for C, H, W, ph, pw, B in ((256, 160, 160, 8, 64, 1), (64, 176, 320, 11, 96, 1),
         ba = T(lambda: ext.backward(g, Rr, f.shape, 0.25), 20)
         bl = T(lambda: ext.backward(g, Rr, f.shape, 0.25, path=ext.PATH_TILED_LISTS), 20)
         bk = T(lambda: ext.backward(g, Rr, f.shape, 0.25, path=ext.PATH_TILED_INKERNEL), 20)
+        bb = T(lambda: ext.backward(g, Rr, f.shape, 0.25, path=ext.PATH_TILED_BUCKETS), 20)
         ratio = R * C * ph * pw / (B * C * H * W)
-        print(f"B={B} C={C} {H}x{W} {ph}x{pw} R={R:4d} out/map={ratio:6.2f}  fwd direct {fd:7.1f} tiled {ft:7.1f} auto {fa:7.1f} | bwd direct {bd:8.1f} tiled {bt:7.1f} (lists in HBM {bl:7.1f}, in-kernel {bk:7.1f}) auto {ba:8.1f}")
+        print(f"B={B} C={C} {H}x{W} {ph}x{pw} R={R:4d} out/map={ratio:6.2f}  fwd direct {fd:7.1f} tiled {ft:7.1f} auto {fa:7.1f} | bwd direct {bd:8.1f} tiled {bt:7.1f} (exact lists {bl:7.1f}, buckets {bb:7.1f}, in-kernel {bk:7.1f}) auto {ba:8.1f}")

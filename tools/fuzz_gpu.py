@@ -66,7 +66,7 @@ for t in range(trials):
     gw = O.backward_c(gout_o, r_o, f.shape, s)
     sc = max(1.0, float(np.abs(gw).max()))
     G = torch.from_numpy(gout).cuda()
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL, ext.PATH_TILED_ATOMIC):
         g = ext.backward(G, Rr, f.shape, s, path=p).cpu().numpy()
         e = float(np.abs(g - gw).max())
         if not e <= 1e-4 * sc:
