@@ -77,15 +77,15 @@ int rroi_align_release_launcher_scratch(void);
 #define RROI_PATH_TILED_ATOMIC 3 /* backward only: the tiled scatter with fp32 atomics (the
                                     default tiled backward is an atomic-free gather)         */
 #define RROI_PATH_TILED_LISTS 4  /* backward only: the gather over per-pixel lists built in HBM by
-                                    count / scan / fill launches (what TILED runs for C > 128,
-                                    and for C > 64 when the lists are long)                  */
+                                    count / scan / fill launches (what TILED runs beyond a mean of
+                                    192 list entries per map pixel)                          */
 #define RROI_PATH_TILED_BUCKETS 6 /* backward only (round 3): the gather over per-pixel lists built in ONE pass --
                                     fixed-capacity buckets per pixel plus overflow chains: no count pass, no
-                                    scan (what TILED runs where TILED_LISTS used to, while the average list
-                                    is short enough for buckets)                                           */
+                                    scan.  What AUTO / TILED run up to a mean of 192 list entries per map
+                                    pixel; any density is accepted when named (long lists walk the chains) */
 #define RROI_PATH_TILED_INKERNEL 5 /* backward only: the gather that finds each map tile's bins
-                                    inside the kernel (what TILED runs for C <= 64, and for C <= 128
-                                    while there are at most 8 bins per map pixel)            */
+                                    inside the kernel, no lists in HBM (only when named; round 2's
+                                    choice for C <= 64)                                       */
 
 /* Bytes of scratch the tiled path needs for this problem (0 for the direct
  * path).  The caller owns the scratch; its contents are dead after the call. */
@@ -142,7 +142,7 @@ int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batc
  * the recognition head runs in channels_last -- which the gather formulation consumes in place (no
  * relayout pass).  bottom_diff_layout: NCHW (B, C, H, W) as above, or NHWC storage (B, H, W, C),
  * written directly (no relayout back) for a channels_last backbone.  Either NHWC needs
- * C % 4 == 0 and path AUTO, TILED, TILED_LISTS or TILED_INKERNEL. */
+ * C % 4 == 0 and path AUTO, TILED, TILED_LISTS, TILED_BUCKETS or TILED_INKERNEL. */
 int rroi_align_backward_layout_hip(const float* top_diff, int top_diff_layout, int bottom_diff_layout,
                                    float spatial_scale, int batch_size, int num_rois, int height,
                                    int width, int channels, int pooled_height, int pooled_width,

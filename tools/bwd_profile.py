@@ -12,9 +12,10 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "fots.pytorch_amd"), os.path.join(ROOT,
 import workloads as Wk  # noqa: E402
 from rroi_align._ext import rroi_align as ext  # noqa: E402
 
-f, r = Wk.bench_inputs()
+CH = int(os.environ.get("RROI_BWD_C", "256"))   # channel count (configs[2]: 256)
+f, r = Wk.bench_inputs(C=CH)
 R = torch.from_numpy(r).cuda()
-g = torch.randn(512, 256, 8, 64, device="cuda")
+g = torch.randn(512, CH, 8, 64, device="cuda")
 B, C, H, W = f.shape
 nb = ext._lib.rroi_align_backward_workspace_bytes(B, C, H, W, 512, 8, 64)
 ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
