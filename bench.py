@@ -282,6 +282,33 @@ def run(args):
         if not one_device and len(set(uuids)) != world:
             raise SystemExit("bench.py: %d ranks but the devices are %s -- two ranks share a GPU" % (world, uuids))
 
+    # spread of the call (median / p10 / p90 over individually bracketed calls; an event between
+    # two launches costs ~1-2 us of its own, so these sit above the back-to-back average) and the two
+    # sensitivity points -- every bin active (w / h = 8) and axis-aligned ROIs (angle = 0)
+    step_stats = sensitivity = None
+    if world == 1:
+        sensitivity = {}
+        keep = rois.clone()
+        for name, edit in (("default_draw", lambda r: None), ("all_active", lambda r: r[:, 4].copy_(r[:, 3] * 8.0)),
+                           ("axis_aligned", lambda r: r[:, 5].zero_())):
+            rois.copy_(keep)
+            edit(rois)
+            # a change of the ROI set is followed by a transient of a few hundred launches (seen up to 70 us per
+            # call decaying to 57; tools/sensitivity_probe.py): warm up in chunks until two agree within 1 %
+            prev = event_loop(lambda: launch(ext.STAGE_ALL), 50, 100)
+            for _ in range(20):
+                cur = event_loop(lambda: launch(ext.STAGE_ALL), 0, 100)
+                settled = abs(cur - prev) <= 0.01 * prev
+                prev = cur
+                if settled:
+                    break
+            ms = event_loop(lambda: launch(ext.STAGE_ALL), 0, 200)
+            sensitivity[name] = {"ms_per_call": round(ms, 5), "ROIs/s": round(R / (ms * 1e-3), 1)}
+        sensitivity["what"] = ("the same call, same loop: the default draw (control), w = 8 h for every ROI (no masked "
+                               "bins), angle = 0 (rows of a crop are rows of the map); not part of `value`")
+        rois.copy_(keep)
+        del keep
+
     # calibration of the bound on this box: a plain device fill of the same 256 MiB output buffer
     fill_ms = event_loop(lambda: out.fill_(0.0), 10, 40)
     launch(ext.STAGE_ALL)  # leave the real result in `out`
@@ -331,6 +358,24 @@ def run(args):
                 raise RuntimeError(f"rroi_align_backward_layout_hip -> {st}")
         bwd_cl_ms = event_loop(bwd_cl, 10, 50)
         del gout, gout_cl, ws_b, gin
+
+    # spread of the call, measured LAST among the kernel timings (200 interleaved event records leave the
+    # runtime ~3.5 us per call slower for what follows in the process -- measured, cause not pursued)
+    if world == 1:
+        n_s = 200
+        for _ in range(20):
+            launch(ext.STAGE_ALL)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_s + 1)]
+        evs[0].record()
+        for i in range(n_s):
+            launch(ext.STAGE_ALL)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        d = np.sort(np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n_s)]))
+        del evs
+        step_stats = {"n": n_s, "median": round(float(np.median(d)), 5), "p10": round(float(d[n_s // 10]), 5),
+                      "p90": round(float(d[(9 * n_s) // 10]), 5),
+                      "how": "one HIP event after every call, 200 calls, differences of consecutive events"}
 
     # configs[4] on the side: the end-to-end inference pipeline (backbone + RoIRotate + CRNN head)
     e2e = None
@@ -396,10 +441,12 @@ def run(args):
                                           "kernel trace does not)" % (KERNEL_TIMED, KERNEL_WARM)},
                      "prologue_ms_avg": round(prologue_ms, 5),
                      "whole_call_ms_events": round(step_events_ms, 5),
+                     "whole_call_ms_spread": step_stats,
                      "calibrated": {"what": "torch fill_ of the 256 MiB output buffer on this GPU (40 back-to-back)",
                                     "GB/s": round(fill_gbs, 1), "frac_of_it": round(achieved / fill_gbs, 4)}},
         "cpu_baseline": cpu,
         "extra": {
+            "sensitivity": sensitivity,
             "ranks": ranks_info,
             "with_gather_ms": None if with_gather_ms is None else round(with_gather_ms, 4),
             "with_allreduce_grad_ms": None if with_allreduce_ms is None else round(with_allreduce_ms, 4),

@@ -109,9 +109,10 @@ bool shape_ok(int batch_size, int num_rois, int height, int width, int channels,
 // multiple of lcm(nchunks, 8) so that blockIdx % nchunks is also stable per XCD.
 int g_waves_per_cu = 12;
 
-// the split forward kernel: workgroups of a gatherer and a storer wave; 90 VGPRs -> 5 waves per SIMD = 10
-// workgroups per CU (12.1 KB of LDS each); a larger grid would run its surplus as a second round
-int g_split_wgs_per_cu = 10;
+// the split forward kernel: workgroups of a gatherer and a storer wave; 62-64 VGPRs under __launch_bounds__(128, 6)
+// and 12.1 KB of LDS (10 granules of 1280 B) -> 12 workgroups per CU; a larger grid would run its surplus as a second
+// round.  (Round 3's first form, <EARLY = 2, OCC = 5, HID = 2>: 90 VGPRs, 10 per CU.)
+int g_split_wgs_per_cu = 12;
 int g_fwd_split = 1;  // 1: loads and stores in different waves (rroi_fwd_split_kernel) for NCHW crops
 
 int tiled_grid(long items, int nchunks, int per_cu = 0)
@@ -546,14 +547,20 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
                        ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,        \
                        batch_size, nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
         const int sgrid = tiled_grid((long)num_rois * ntiles, nchunks, g_split_wgs_per_cu);
+        // EARLY = 0, six waves per SIMD, double-buffered HI groups, 12 workgroups per CU (tools/split_explore.py, three
+        // to four interleaved rounds): as fast as <2, 1, 5, 2> with 10 per CU on the default draw (step 53.5-53.75
+        // against 53.45-53.85 us, gather alone 44.5-44.9 against 45.5-46.1) and faster where the gatherer waves are the
+        // critical path -- every bin active (w = 8 h): step 55.4-55.9 against 57.0-57.3 us
 #define RROI_LAUNCH_SPLIT(VEC)                                                                           \
-    hipLaunchKernelGGL((rroi_fwd_split_kernel<VEC, 2>), dim3(sgrid), dim3(2 * kWave), 0, stream, map,     \
+    hipLaunchKernelGGL((rroi_fwd_split_kernel<VEC, 2, 0, 1, 6, 3>), dim3(sgrid), dim3(2 * kWave), 0, stream, map, \
                        ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size, \
                        nchunks, ntiles, lay, dt, dp, g_fwd_dbg | (launcher_rest ? 32 : 0))
         // channels-last crops: the split kernel behind the prologue (55.2 against 56.4-58.6 us at cfg2); with
         // channels-last features consumed in place the one-wave kernel is as fast or faster (51.6 against 52.3)
         if (out_nhwc && !zero_copy && g_fwd_split && g_store_aux == 2)
-            hipLaunchKernelGGL((rroi_fwd_split_kernel<true, 2, 2, 1, 5, 2, true>), dim3(sgrid), dim3(2 * kWave), 0, stream,
+            // (five waves per SIMD: 10 workgroups per CU are resident, and no more are launched)
+            hipLaunchKernelGGL((rroi_fwd_split_kernel<true, 2, 2, 1, 5, 2, true>),
+                               dim3(tiled_grid((long)num_rois * ntiles, nchunks, 10)), dim3(2 * kWave), 0, stream,
                                map, ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,
                                nchunks, ntiles, lay, dt, dp, g_fwd_dbg);
         else if (out_nhwc)
@@ -565,7 +572,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     hipLaunchKernelGGL((rroi_fwd_split_kernel<true, 2, E, 1, O, H>), dim3(sgrid), dim3(2 * kWave), 0, stream, \
                        map, ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size, \
                        nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
-        else if (g_fwd_split == 2) RROI_LAUNCH_SPLIT_X(0, 6, 3);
+        else if (g_fwd_split == 2) RROI_LAUNCH_SPLIT_X(2, 5, 2);   // round 3's first shipped form (with 10 per CU)
         else if (g_fwd_split == 3) RROI_LAUNCH_SPLIT_X(1, 6, 3);
         else if (g_fwd_split == 4) RROI_LAUNCH_SPLIT_X(2, 6, 3);
         else if (g_fwd_split == 5) RROI_LAUNCH_SPLIT_X(2, 5, 3);

@@ -287,6 +287,9 @@ int main(int argc, char** argv)
         hr[i * 6 + 3] = h;
         hr[i * 6 + 4] = h * (4 + 4 * U(rng));
         hr[i * 6 + 5] = -90 + 180 * U(rng);
+        // SURVEY 8(d) sensitivity points: every bin active / axis-aligned ROIs
+        if (getenv("RROI_KB_ALL_ACTIVE")) hr[i * 6 + 4] = h * 8;
+        if (getenv("RROI_KB_AXIS")) hr[i * 6 + 5] = 0;
     }
     CK(hipMemcpy(feat, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(rois_d, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));

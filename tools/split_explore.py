@@ -40,6 +40,8 @@ def timeit(fn, warm=200, iters=500):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     f, r = Wk.bench_inputs()
+    if os.environ.get("RROI_ALL_ACTIVE"):   # SURVEY 8(d) sensitivity point: w = 8 h, no masked bins
+        r[:, 4] = r[:, 3] * 8
     F, R = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
     n, C, H, W = R.shape[0], F.shape[1], F.shape[2], F.shape[3]
     top = torch.empty((n, C, 8, 64), device="cuda")
@@ -59,7 +61,7 @@ def main():
     torch.cuda.synchronize()
     res = {"split_equals_tiled": bool(torch.equal(top, ref))}
     for rnd in range(rounds):
-        for name, on, wgs in (("tiled", 0, -1), ("split10", 1, 10), ("e0o6h3w12", 2, 12), ("e1o6h3w12", 3, 12), ("e2o6h3w12", 4, 12), ("e2o5h3w10", 5, 10), ("e0o6h1w12", 6, 12)):
+        for name, on, wgs in (("tiled", 0, -1), ("split10", 1, 10), ("e0o6h3w12", 2, 12), ("e1o6h3w12", 3, 12), ("e2o6h3w12", 4, 12), ("e2o5h3w10", 5, 10), ("e0o6h1w12", 6, 12), ("split8", 1, 8), ("split12", 1, 12)):
             lib.rroi_align_debug_set_fwd_split(on, wgs)
             res.setdefault(name + "_step", []).append(timeit(lambda: call(3)))
             res.setdefault(name + "_gather", []).append(timeit(lambda: call(2)))
