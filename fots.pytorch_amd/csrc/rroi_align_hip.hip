@@ -227,12 +227,16 @@ BwdWorkspace carve_bwd(void* ws, int batch_size, int channels, int height, int w
     w.cnt_bytes = align_up(nkeys * sizeof(int), 256);
     const size_t off_bytes = align_up((nkeys + 1) * sizeof(unsigned), 256);
     const size_t bsum_bytes = align_up((size_t)w.scan_blocks * sizeof(unsigned), 256);
-    // bucket capacity: ~3x the average list (about 2 pairs per bin over the map's pixels), a power of two in
-    // [16, 128]; a denser problem keeps the exact count / scan / fill lists
+    // bucket capacity: ~3x the average list (about 2 pairs per bin over the map's pixels), a power of two from 16
+    // up -- as far as the buckets stay within max(64 MB, twice the exact lists' bytes): only the entries in use are
+    // ever read, a large bucket costs address space, not bandwidth.  Where that cap leaves the bucket below the
+    // AVERAGE list, most of a list would live in the (slow) chains and AUTO / TILED keep count / scan / fill.
     const double avg = 2.0 * (double)R * NB / ((double)batch_size * height * width);
+    const size_t bucket_cap = std::max<size_t>((size_t)64 << 20, 2 * 4 * R * NB * sizeof(uint2));
     w.kshift = 4;
-    while ((1u << w.kshift) < 3.0 * avg && w.kshift < 7) ++w.kshift;
-    w.bucket_pref = avg <= 192.0;   // denser: most of a list would live in the (slow) chains
+    while ((1u << w.kshift) < 3.0 * avg && w.kshift < 12 && (nkeys << (w.kshift + 1)) * sizeof(uint2) <= bucket_cap)
+        ++w.kshift;
+    w.bucket_pref = (double)(1u << w.kshift) >= avg;
     w.bucket_ok = (nkeys << w.kshift) < (1ull << 32) && 4 * R * NB < (1ull << 31);
     const size_t bucket_bytes = w.bucket_ok ? align_up((nkeys << w.kshift) * sizeof(uint2), 256) : 0;
     const size_t ov_bytes = w.bucket_ok ? align_up(4 * R * NB * sizeof(uint4), 256) : 0;
@@ -281,7 +285,15 @@ bool pick_tiled_bwd(int batch_size, int channels, int height, int width, int num
 {
     const double out_elems = (double)num_rois * channels * NB;
     const double map_elems = (double)batch_size * channels * height * width;
-    return out_elems >= 0.5e6 && out_elems >= map_elems / 16;
+    // the scatter's cost is the memset of the map plus its atomics: with the one-pass lists (round 3) the gather
+    // wins from ~0.2 M gradient elements up (one 64 x 176 x 320 map, R = 4, 0.27 M: 26-27 us whatever the draw, the
+    // scatter 18.6 or 41.4 depending on how the four ROIs overlap), and below that wherever the map alone is 8 M
+    // elements (eight 64 x 160 x 160 maps, R = 4: 41.7 against 48.0 us); tools/crossover.py, tools/bucket_ab.py
+    // ... unless the map dwarfs the gradient: the gather path moves the whole map three times (chunk-major gradient
+    // written, read back, written as NCHW), the scatter once (its memset), and the scatter's atomics cost ~110 us
+    // per million gradient elements (R = 16, C = 256: 250 us for 2.1 M)
+    if (2.0 * map_elems * 4.0 / 7.0e6 > 110.0 * out_elems / 1.0e6 - 21.0 && map_elems >= 32.0e6) return false;
+    return out_elems >= 0.2e6 || map_elems >= 8.0e6;
 }
 
 int g_store_aux = 2;   // cache policy of the output stores (see buf_store); 16 / 0 for exploration
@@ -793,8 +805,10 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
     // overflow chains, rroi_backward_kernels.h) instead of count / scan / fill.  Measured (tools/crossover.py,
     // tools/bucket_ab.py, profiles/r03_crossover_buckets.txt; us per call, buckets / exact lists / K3t): cfg3 129 /
     // 144 / 179;  C = 256 R = 16 37 / 53 / 48;  C = 64 176x320 R = 128 40 / 48 / 43;  8 images of 160x160 R = 64
-    // 49 / 61 / 61 -- they win everywhere up to ~128 list entries per map pixel (74 / 89 / 164 there) and lose
-    // beyond (512 per pixel: 200 / 128 / 318), where most of a list lives in the chains: bucket_pref.
+    // 49 / 61 / 61 -- they win wherever the bucket holds at least the average list (128 entries per pixel in buckets
+    // of 128: 74 / 89 / 164) and lose where most of a list lives in the chains (512 per pixel in buckets of 128:
+    // 200 / 128 / 318): the bucket grows with the density as far as carve_bwd's cap lets it, bucket_pref says if
+    // that was far enough.
     const bool buckets = gather && ws.bucket_ok && gather_choice_is_open(path) &&
                          (path == RROI_PATH_TILED_BUCKETS || (ws.bucket_pref && g_bwd_buckets));
     const bool lists = buckets || path == RROI_PATH_TILED_LISTS || !inkernel_ok ||

@@ -77,12 +77,12 @@ int rroi_align_release_launcher_scratch(void);
 #define RROI_PATH_TILED_ATOMIC 3 /* backward only: the tiled scatter with fp32 atomics (the
                                     default tiled backward is an atomic-free gather)         */
 #define RROI_PATH_TILED_LISTS 4  /* backward only: the gather over per-pixel lists built in HBM by
-                                    count / scan / fill launches (what TILED runs beyond a mean of
-                                    192 list entries per map pixel)                          */
+                                    count / scan / fill launches (what TILED runs where the memory
+                                    cap leaves a bucket below the mean list)                 */
 #define RROI_PATH_TILED_BUCKETS 6 /* backward only (round 3): the gather over per-pixel lists built in ONE pass --
                                     fixed-capacity buckets per pixel plus overflow chains: no count pass, no
-                                    scan.  What AUTO / TILED run up to a mean of 192 list entries per map
-                                    pixel; any density is accepted when named (long lists walk the chains) */
+                                    scan.  What AUTO / TILED run (the bucket grows with the density, 16 ..
+                                    4096 entries, under a memory cap); any density is accepted when named    */
 #define RROI_PATH_TILED_INKERNEL 5 /* backward only: the gather that finds each map tile's bins
                                     inside the kernel, no lists in HBM (only when named; round 2's
                                     choice for C <= 64)                                       */

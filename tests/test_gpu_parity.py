@@ -139,7 +139,7 @@ def test_sincos_recipe_matches_host_libm(ext):
     assert bad == 0, f"{bad} of {2 * len(deg)} sin/cos values differ between ocml and glibc"
 
 
-@pytest.mark.parametrize("path", ["direct", "tiled", "tiled_lists", "tiled_inkernel", "tiled_atomic"])
+@pytest.mark.parametrize("path", ["direct", "tiled", "tiled_lists", "tiled_buckets", "tiled_inkernel", "tiled_atomic"])
 @pytest.mark.parametrize("name", ["cfg1", "mid_c64", "c70_odd", "c5_pad", "batch3", "train_11xceil"])
 def test_backward_vs_oracle(ext, oracle, name, path):
     f, r, ph, pw, s = SHAPES[name]()

@@ -36,7 +36,8 @@ def case(label, R, C, H, W, img, ph=8, pw=64, batch=1, cl=False):
     outs = {}
     for rep in range(3):
         for name, path in (("lists", ext.PATH_TILED_LISTS), ("buckets", ext.PATH_TILED_BUCKETS),
-                           ("inkernel", ext.PATH_TILED_INKERNEL), ("auto", ext.PATH_AUTO)):
+                           ("inkernel", ext.PATH_TILED_INKERNEL), ("auto", ext.PATH_AUTO)) + (
+                               (("direct", ext.PATH_DIRECT),) if R <= 64 and not cl else ()):
             fn = lambda: ext.backward(g, Rt, f.shape, 0.25, path=path, channels_last_grad=cl)  # noqa: E731
             try:
                 t = timed(fn)
@@ -60,3 +61,8 @@ case("denser 1024x64 32x32 (avg 1024)", 1024, 64, 32, 32, 128)
 case("densest 512x64 16x16 (avg 2048)", 512, 64, 16, 16, 64)
 case("small 16x256 160x160", 16, 256, 160, 160, 640)
 case("small 4x64 176x320", 4, 64, 176, 320, 1280, ph=11, pw=96)
+case("cfg4 on one GPU: 4096x256 160x160", 4096, 256, 160, 160, 640)
+case("2048x256 160x160", 2048, 256, 160, 160, 640)
+case("few ROIs, 16 maps: 8x256 160x160 b16", 8, 256, 160, 160, 640, batch=16)
+case("few ROIs, 8 maps: 4x64 160x160 b8", 4, 64, 160, 160, 640, ph=11, pw=100, batch=8)
+case("few ROIs: 32x64 176x320", 32, 64, 176, 320, 1280, ph=11, pw=96)
