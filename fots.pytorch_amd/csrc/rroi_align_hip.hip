@@ -113,6 +113,9 @@ int g_waves_per_cu = 12;
 // and 12.1 KB of LDS (10 granules of 1280 B) -> 12 workgroups per CU; a larger grid would run its surplus as a second
 // round.  (Round 3's first form, <EARLY = 2, OCC = 5, HID = 2>: 90 VGPRs, 10 per CU.)
 int g_split_wgs_per_cu = 12;
+int g_shift_parts = 0;      // exploration: > 0 forces the runs per (roi, chunk) block
+int g_shift_wgs_per_cu = 0;   // exploration: > 0 overrides the SHIFT kernels' workgroups per CU
+int g_fwd_shift = 1;  // 1: crops with PH * PW % 16 != 0 take the split kernel's SHIFT form
 int g_fwd_split = 1;  // 1: loads and stores in different waves (rroi_fwd_split_kernel) for NCHW crops
 
 int tiled_grid(long items, int nchunks, int per_cu = 0)
@@ -559,6 +562,25 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
                        ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,        \
                        batch_size, nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
         const int sgrid = tiled_grid((long)num_rois * ntiles, nchunks, g_split_wgs_per_cu);
+        // SHIFT kernels: a (roi, chunk) block of ntiles tiles is cut into `parts` runs for the workgroups of its chunk.
+        // Every cut costs two partial sectors per channel row, every run shorter than the block buys parallelism:
+        // measured (tools/align_probe.py, 11 x 100 and 11 x 83 crops, R = 8 ... 2048, C = 64 / 256) the best cut is
+        // about one run per workgroup while the ROIs are fewer than the workgroups of a chunk -- 2 for R = 512 on
+        // 1280 slots (39 us; 1: 49, 3: 46, 9: 51), 6 for R = 128 on 1024 (18; 2: 32, 15: 24) -- and none beyond.
+        auto shift_parts = [&](int wgs_per_cu) {
+            if (g_shift_parts > 0) return std::min(g_shift_parts, ntiles);
+            const long per_roi = std::max(1L, (long)num_cus() * wgs_per_cu / nchunks) / std::max(1, num_rois);
+            long m = per_roi <= 3 ? per_roi : 3 * per_roi / 4;
+            m = std::max(1L, std::min<long>(m, ntiles));
+            while (m > 1 && (m - 1) * ceil_div(ntiles, (int)m) >= ntiles) --m;   // no empty last part
+            return (int)m;
+        };
+        // small problems stay with the strided items (latency-bound: 12 workgroups per CU all busy beats whole
+        // sectors) -- from 5 workgroups of a chunk per roi up when the rows are multiples of 16 bytes (R = 128, C = 64,
+        // 11 x 100: 15.3 against 15.1 us; R = 32: 6.3 against 8.2), from 32 up otherwise, where the strided form
+        // stores dwords (R = 32, C = 64, 11 x 83: 10.0 against 9.2; R = 8: 5.1 against 7.3; R = 128: 51 against 18)
+        const long split_slots_per_roi = std::max(1L, (long)num_cus() * g_split_wgs_per_cu / nchunks) / std::max(1, num_rois);
+        const bool shift_pays = g_fwd_shift == 2 || split_slots_per_roi < (NB % 4 == 0 ? 5 : 32);
         // EARLY = 0, six waves per SIMD, double-buffered HI groups, 12 workgroups per CU (tools/split_explore.py, three
         // to four interleaved rounds): as fast as <2, 1, 5, 2> with 10 per CU on the default draw (step 53.5-53.75
         // against 53.45-53.85 us, gather alone 44.5-44.9 against 45.5-46.1) and faster where the gatherer waves are the
@@ -591,6 +613,23 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         else if (g_fwd_split == 6) RROI_LAUNCH_SPLIT_X(0, 6, 1);
 #undef RROI_LAUNCH_SPLIT_X
 #endif
+        // crops whose rows are not whole 64-byte sectors: runs of tiles per workgroup, sector-aligned store windows
+        // (rroi_fwd_split_kernel<..., SHIFT>); 14.2 KB of LDS -> 10 workgroups per CU
+#define RROI_LAUNCH_SHIFT(S, O, W)                                                                            \
+    do {                                                                                                      \
+        const int wpc = g_shift_wgs_per_cu > 0 ? g_shift_wgs_per_cu : W;                                      \
+        const int sp = shift_parts(wpc);                                                                      \
+        hipLaunchKernelGGL((rroi_fwd_split_kernel<true, 2, 0, 1, O, 3, false, S>),                            \
+                           dim3(tiled_grid((long)num_rois * sp, nchunks, wpc)), dim3(2 * kWave), 0, stream, map, \
+                           ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,   \
+                           nchunks, ntiles, lay, dt, dp, (g_fwd_dbg & 255) | (launcher_rest ? 32 : 0) | (sp << 8)); \
+    } while (0)
+        else if ((g_fwd_split || launcher_rest) && g_store_aux == 2 && (NB % 16 != 0 || g_fwd_shift == 2) && g_fwd_shift && shift_pays) {
+            // 1: every row starts a multiple of 16 bytes into its sector; 2: any offset
+            if (NB % 4 == 0 && reinterpret_cast<size_t>(top_data) % 16 == 0) RROI_LAUNCH_SHIFT(1, 5, 10);   // 96 VGPRs, 14.2 KB of LDS: 10 workgroups per CU
+            else RROI_LAUNCH_SHIFT(2, 4, 8);                                    // 120 VGPRs: 8 per CU
+        }
+#undef RROI_LAUNCH_SHIFT
         else if ((g_fwd_split || launcher_rest) && g_store_aux == 2 && NB % 4 != 0) RROI_LAUNCH_SPLIT(false);
         else if ((g_fwd_split || launcher_rest) && g_store_aux == 2) RROI_LAUNCH_SPLIT(true);
         else if (NB % 4 != 0) RROI_LAUNCH_FWD(false, 2);
@@ -644,6 +683,14 @@ int rroi_align_debug_set_fwd_split(int on, int wgs_per_cu)
     const int old = g_fwd_split;
     if (on >= 0) g_fwd_split = on;
     if (wgs_per_cu > 0) g_split_wgs_per_cu = wgs_per_cu;
+    return old;
+}
+int rroi_align_debug_set_fwd_shift(int v, int wgs_per_cu, int parts)
+{
+    const int old = g_fwd_shift;
+    if (v >= 0) g_fwd_shift = v;
+    if (wgs_per_cu >= 0) g_shift_wgs_per_cu = wgs_per_cu;
+    if (parts >= 0) g_shift_parts = parts;
     return old;
 }
 int rroi_align_debug_set_bwd_buckets(int v)

@@ -646,7 +646,8 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
 // __syncthreads() nothing here makes the compiler emit s_waitcnt vmcnt(0).
 __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool VEC_STORE, int AUX, int EARLY = 2, int MINOR = 1, int OCC = 5, int HID = 2, bool ONHWC = false>
+template <bool VEC_STORE, int AUX, int EARLY = 2, int MINOR = 1, int OCC = 5, int HID = 2, bool ONHWC = false,
+          int SHIFT = 0>
 __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
@@ -676,7 +677,9 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // tile pitch), which admits 14 waves per CU: 12 waves 47.2 us, 13 48.0, 14 48.5 (tools/kbench abl)
     // -- the kernel is bound by the write path, not by latency -- and the spare-column writes are
     // 4-way bank-conflicted (SQ_LDS_BANK_CONFLICT 40 % instead of 32 % of the LDS cycles): not kept.
-    __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride + 3 * kTStride + 32];
+    // (SHIFT: plus the carried groups, 16 floats per channel row, behind the tile)
+    constexpr unsigned kCyBase = kChunk * kTStride + 3 * kTStride + 32;
+    __shared__ __attribute__((aligned(16))) float T[kCyBase + (SHIFT ? kChunk * 16 : 0)];
     // tap records of two items: item i+1 is sampled out of one set while the other is being
     // built for item i+2
     constexpr int kRecs = kMaxGroups * kBinsPerIter;
@@ -896,6 +899,159 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         }
     };
 
+    // SHIFT (crops whose rows are not multiples of 64 bytes: PH * PW % 16 != 0).  A 256-byte row segment that
+    // starts 16, 32 or 48 bytes into a 64-byte sector ends in one too: two partial sectors per row and tile, each
+    // completed later by ANOTHER workgroup -- and HBM pays for a partial sector with a read-modify-write
+    // (tools/align_probe.py: 11 x 100 crops 58 us against 28 us for 11 x 96; PH * PW % 4 != 0, where the stores
+    // were dwords: 215 us).  Here a workgroup owns a RUN of consecutive tiles of one (roi, chunk) block and
+    // every row's store window is shifted left by h = (the row's float offset in memory) mod 16, so that it starts
+    // on a sector: the h columns that fall out on the right are CARRIED in LDS (Cy: the previous tile's last four
+    // 4-float groups per row) into the next tile's window.  Partial sectors are left at the ends of a row and of a
+    // run only.  p = j + h is a float's position in the window, j its column in the tile (j < 0: carried).
+    // Between the barriers the storer does what drain_tile does -- one 16-byte LDS read per row set, of the group
+    // its window starts in (two when h is not a multiple of 4: the window then straddles two groups) -- so the
+    // gatherer waits no longer for T than without the shift; masks, the sub-group shift and the carry follow.
+    float* const Cy = T + kCyBase;
+    auto grp_idx = [&](unsigned r, int g) -> unsigned {   // float index in T[] of 4-float group g of row r
+        return g >= 0 ? r * kTStride + ((((unsigned)g) ^ (r >> 3)) << 2) : kCyBase + r * 16u + (unsigned)(4 + g) * 4u;
+    };
+    auto drain_shift = [&](unsigned n, unsigned t, unsigned long long cur_mask, bool skip, bool carry_ok, bool flush) {
+        const unsigned L = lane & 15u;
+        const unsigned nb15 = (unsigned)NB & 15u;
+        // float index of (roi n, first channel of the chunk, bin 0), modulo a sector -- out's own alignment included
+        const unsigned h0 = (((unsigned)(reinterpret_cast<size_t>(out) >> 2) & 15u) +
+                             (((n & 15u) * ((unsigned)C & 15u) + ((k * kChunk) & 15u)) & 15u) * nb15) & 15u;
+        // SHIFT == 1: every row's h is a multiple of 4 (PH * PW % 4 == 0 and `out` 16-byte aligned: the host checks)
+        constexpr bool sub = SHIFT == 2;
+        const int left = NB - (int)(t * kTileBins);            // columns of this tile that are bins (>= 1)
+        const bool interior = carry_ok && left >= kTileBins;   // every position of every window is a bin of this run
+        auto masked = [&](v4f x, int g) -> v4f {               // bins in no group are zero; carried groups already are
+            const unsigned m = g >= 0 ? (unsigned)(cur_mask >> (4 * g)) & 15u : 15u;
+            return v4f{(m & 1u) ? x.x : 0.f, (m & 2u) ? x.y : 0.f, (m & 4u) ? x.z : 0.f, (m & 8u) ? x.w : 0.f};
+        };
+        auto tile_at = [&](unsigned r, int j) -> float {       // one column (edge tiles only)
+            const float x = T[grp_idx(r, j >> 2) + (unsigned)(j & 3)];
+            return (j < 0 || ((cur_mask >> (j & 63)) & 1ull)) ? x : 0.0f;
+        };
+        v4f o[kChunk / 4];
+        if (!sub) {
+#pragma unroll
+            for (int s4 = 0; s4 < kChunk / 4; ++s4) {
+                const unsigned r = s4 * 4 + row0;
+                const int g = (int)L - (int)(((h0 + r * nb15) & 15u) >> 2);
+                o[s4] = *reinterpret_cast<const v4f*>(T + grp_idx(r, g));
+            }
+        } else {
+            // window element e = column 4 (L - a) + e - b: from group L - a (e >= b) or the one before it
+#pragma unroll
+            for (int q2 = 0; q2 < kChunk / 4; q2 += 2) {
+                v4f X[2], Y[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned r = (q2 + i) * 4 + row0;
+                    const int g = (int)L - (int)(((h0 + r * nb15) & 15u) >> 2);
+                    X[i] = *reinterpret_cast<const v4f*>(T + grp_idx(r, g));
+                    Y[i] = *reinterpret_cast<const v4f*>(T + grp_idx(r, g - 1));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned r = (q2 + i) * 4 + row0;
+                    const unsigned h = (h0 + r * nb15) & 15u;
+                    const int g = (int)L - (int)(h >> 2);
+                    const unsigned bsh = h & 3u;
+                    const v4f x = masked(X[i], g), y = masked(Y[i], g - 1);
+                    // z[4 + e - b] of z = {y, x}
+                    const float z1 = y.y, z2 = y.z, z3 = y.w, z4 = x.x, z5 = x.y, z6 = x.z;
+                    o[q2 + i] = bsh == 0 ? x
+                              : bsh == 1 ? v4f{z3, z4, z5, z6}
+                              : bsh == 2 ? v4f{z2, z3, z4, z5}
+                                         : v4f{z1, z2, z3, z4};
+                }
+            }
+        }
+        // the groups to carry: lane = (row, 12 + lane / 32) and the group two further on
+        const unsigned cr = lane & 31u;
+        const int cg = 12 + (int)(lane >> 5);
+        v4f c0 = *reinterpret_cast<const v4f*>(T + grp_idx(cr, cg));
+        v4f c1 = *reinterpret_cast<const v4f*>(T + grp_idx(cr, cg + 2));
+        // the <= 3 floats in front of / behind the whole 16-byte pieces of a row's valid positions (edge tiles
+        // only): lane = (row, i), two passes -> fix[0..1] head, fix[2..3] tail
+        float fix[4] = {0.f, 0.f, 0.f, 0.f};
+        const unsigned fr = lane & 31u, fi = lane >> 5;
+        const unsigned fh = (h0 + fr * nb15) & 15u;
+        const int pl = carry_ok ? 0 : (int)fh;                       // first valid position of row fr
+        const int ph = min(kTileBins, left + (int)fh);               // one past its last
+        if (!interior && sub) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int pa = pl + (int)fi + 2 * ps, pb = (ph & ~3) + (int)fi + 2 * ps;
+                if (pa < ((pl + 3) & ~3) && pa < ph) fix[ps] = tile_at(fr, pa - (int)fh);
+                if (pb < ph && pb >= pl && (ph & ~3) >= ((pl + 3) & ~3)) fix[2 + ps] = tile_at(fr, pb - (int)fh);
+            }
+        }
+        wg_lds_barrier();  // T has been read: the gatherer may blend the next tile into it
+        if (!sub) {
+#pragma unroll
+            for (int s4 = 0; s4 < kChunk / 4; ++s4) {
+                const unsigned r = s4 * 4 + row0;
+                o[s4] = masked(o[s4], (int)L - (int)(((h0 + r * nb15) & 15u) >> 2));
+            }
+        }
+        // (one wave, LDS operations in program order: every read of the old carried groups precedes these writes)
+        *reinterpret_cast<v4f*>(Cy + cr * 16u + (unsigned)(cg - 12) * 4u) = masked(c0, cg);
+        *reinterpret_cast<v4f*>(Cy + cr * 16u + (unsigned)(cg - 10) * 4u) = masked(c1, cg + 2);
+        const bool live = !(dbg & 1) && !skip;
+        float* obase = out + ((size_t)n * C + k * kChunk) * NB;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, chans_here * (unsigned)NB * 4u);
+#pragma unroll
+        for (int s4 = 0; s4 < kChunk / 4; ++s4) {
+            const unsigned r = s4 * 4 + row0;
+            const unsigned h = (h0 + r * nb15) & 15u;
+            const int p0 = (int)(4 * L);
+            const int rl = carry_ok ? 0 : (int)h, rh = min(kTileBins, left + (int)h);
+            const bool whole = interior || (p0 >= rl && p0 + 4 <= rh);
+            // float offset of position p0 within the (roi, chunk) block; never negative where `whole`
+            const unsigned off = (r * (unsigned)NB + t * kTileBins + (unsigned)p0 - h) * 4u;
+            const unsigned o_off = (live && whole && r < chans_here) ? off : kOOB;
+            if (AUX == 2 && s4 < MINOR) buf_store<kMinorAux>(ws, o_off, o[s4]);
+            else buf_store<AUX>(ws, o_off, o[s4]);
+        }
+        if (!interior && sub) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int pa = pl + (int)fi + 2 * ps, pb = (ph & ~3) + (int)fi + 2 * ps;
+                const bool oka = live && fr < chans_here && pa < ((pl + 3) & ~3) && pa < ph;
+                const bool okb = live && fr < chans_here && pb < ph && pb >= pl && (ph & ~3) >= ((pl + 3) & ~3);
+                buf_store1<AUX>(ws, oka ? (fr * (unsigned)NB + t * kTileBins + (unsigned)pa - fh) * 4u : kOOB, fix[ps]);
+                buf_store1<AUX>(ws, okb ? (fr * (unsigned)NB + t * kTileBins + (unsigned)pb - fh) * 4u : kOOB, fix[2 + ps]);
+            }
+        }
+        if (flush && left > kTileBins - 15) {
+            // the columns carried out of the run's (or the row's) last tile: positions [0, h) of the window of tile
+            // t + 1, as far as they are bins.  lane = (row, piece g of 4 floats), g and g + 2
+            const int pend = min((int)fh, left - kTileBins + (int)fh);   // valid positions: p < pend
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int p0 = 4 * ((int)fi + 2 * ps);
+                v4f w;
+                w.x = Cy[fr * 16u + ((unsigned)(16 + p0 + 0 - (int)fh) & 15u)];
+                w.y = Cy[fr * 16u + ((unsigned)(16 + p0 + 1 - (int)fh) & 15u)];
+                w.z = Cy[fr * 16u + ((unsigned)(16 + p0 + 2 - (int)fh) & 15u)];
+                w.w = Cy[fr * 16u + ((unsigned)(16 + p0 + 3 - (int)fh) & 15u)];
+                const unsigned off = (fr * (unsigned)NB + (t + 1) * kTileBins + (unsigned)p0 - fh) * 4u;
+                const bool okr = live && fr < chans_here;
+                buf_store<AUX>(ws, (okr && p0 + 4 <= pend) ? off : kOOB, w);
+                // the piece that holds the end of the valid positions goes out float by float
+                const bool part = okr && p0 < pend && p0 + 4 > pend;
+                if (sub) {
+                    buf_store1<AUX>(ws, (part && p0 + 0 < pend) ? off + 0u : kOOB, w.x);
+                    buf_store1<AUX>(ws, (part && p0 + 1 < pend) ? off + 4u : kOOB, w.y);
+                    buf_store1<AUX>(ws, (part && p0 + 2 < pend) ? off + 8u : kOOB, w.z);
+                }
+            }
+        }
+    };
+
     // The two waves walk the same items.  gfx950 counts loads and stores with ONE in-order counter, so in
     // a wave that does both a load issued after a tile's stores cannot be consumed before those stores are
     // acknowledged (microseconds, with 256 MiB streaming out) -- rroi_fwd_tiled_kernel orders its phases
@@ -905,8 +1061,31 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     //                      first loads of item i | barrier 2: T has been read | phase B -> T
     //   storer:            barrier 1 | tile i-1: T -> registers | barrier 2 | its eight 1 KiB stores, never
     //                      waited for | geometry of item i+1 -> record set p^1
-    unsigned cur = slot;
-    if (cur >= items) return;
+    // Items of this workgroup: every nslots-th one -- or (SHIFT) RUNS of consecutive tiles of one (roi, chunk) block:
+    // a block is cut into `parts` runs of `len` tiles (parts = dbg >> 8, chosen by the host for an even load), run
+    // rho = roi * parts + part, and the workgroup takes the runs slot, slot + nslots, ...  Both waves walk the same
+    // sequence with next(); kEnd ends it.
+    constexpr unsigned kEnd = 0xffffffffu;
+    const unsigned parts = SHIFT ? max(1u, (unsigned)dbg >> 8) : 1u;
+    const unsigned len = (ntiles + parts - 1u) / parts;
+    unsigned run = slot, run_end = 0;   // SHIFT: the current run and one past its last item
+    auto enter_run = [&]() -> unsigned {   // first item of run `run` (kEnd beyond the last run); empty parts are skipped
+        for (;; run += nslots) {
+            if (run >= (unsigned)num_rois * parts) return kEnd;
+            const unsigned rn = run / parts, part = run - rn * parts;
+            if (part * len >= (unsigned)ntiles) continue;
+            run_end = rn * (unsigned)ntiles + min((unsigned)ntiles, (part + 1u) * len);
+            return rn * (unsigned)ntiles + part * len;
+        }
+    };
+    auto next = [&](unsigned c) -> unsigned {
+        if (!SHIFT) return c + nslots < items ? c + nslots : kEnd;
+        if (c + 1u < run_end) return c + 1u;
+        run += nslots;
+        return enter_run();
+    };
+    unsigned cur = SHIFT ? enter_run() : (slot < items ? slot : kEnd);
+    if (cur == kEnd) return;
     if (storer) {
         unsigned n = fdiv(cur, div_tiles), t = cur - n * (unsigned)ntiles;
         unsigned p = 0;
@@ -916,6 +1095,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         // dbg & 32 (the reference-ABI launcher): the crops of ROIs whose image index is >= batch_size have been
         // written by the prologue launch -- they are not zero-filled here
         bool skip_cur = false, skip_prev = false;
+        bool carry_prev = false;   // SHIFT: the tile before `prev` was its left neighbour, stored by this workgroup
         auto plan = [&](unsigned pn, unsigned pt, unsigned pp, unsigned long long& m) {
             const Affine A = aff[pn];
             skip_cur = (dbg & 32) && A.batch >= batch_size;  // (a negative index still yields zeros)
@@ -925,15 +1105,25 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         plan(n, t, 0, mask_cur);
         for (bool have_prev = false;; have_prev = true) {
             wg_lds_barrier();  // 1: records of item `cur` are in set p; the tile of the previous item is in T
-            if (have_prev) drain_tile(n_prev, t_prev, mask_prev, skip_prev);  // T -> registers | barrier 2 | stores
-            else wg_lds_barrier();
-            if (cur >= items) break;
+            if (have_prev) {
+                if (SHIFT) {
+                    // the run ends with `prev` (runs do not cross into the next roi's block)
+                    const bool last = cur != n_prev * (unsigned)ntiles + t_prev + 1u || t_prev + 1u == (unsigned)ntiles;
+                    drain_shift(n_prev, t_prev, mask_prev, skip_prev, carry_prev, last);
+                    carry_prev = !last;
+                } else {
+                    drain_tile(n_prev, t_prev, mask_prev, skip_prev);  // T -> registers | barrier 2 | stores
+                }
+            } else {
+                wg_lds_barrier();
+            }
+            if (cur == kEnd) break;
             n_prev = n;
             t_prev = t;
             mask_prev = mask_cur;
             skip_prev = skip_cur;
-            cur += nslots;
-            if (cur < items) {
+            cur = next(cur);
+            if (cur != kEnd) {
                 n = fdiv(cur, div_tiles);
                 t = cur - n * (unsigned)ntiles;
                 p ^= 1u;
@@ -946,9 +1136,9 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // not urgent: with the gatherer ahead in the issue arbitration the call is 0.7 us shorter (any level > 0)
     __builtin_amdgcn_s_setprio(2);
     unsigned p = 0;
-    for (;; cur += nslots, p ^= 1u) {
+    for (;; cur = next(cur), p ^= 1u) {
         wg_lds_barrier();  // 1: the storer has put this item's records into set p (and our previous tile is complete)
-        if (cur >= items) {
+        if (cur == kEnd) {
             wg_lds_barrier();  // 2
             break;
         }

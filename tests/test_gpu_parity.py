@@ -215,6 +215,36 @@ def test_backward_many_rois_on_one_pixel(ext, oracle):
         assert np.array_equal(g == 0, gwant == 0)
 
 
+@pytest.mark.parametrize("R,C,ph,pw,B", [(300, 64, 11, 83, 1), (300, 64, 11, 100, 2), (700, 40, 7, 50, 1),
+                                         (260, 96, 11, 85, 3), (2100, 32, 3, 21, 1)])
+def test_forward_rows_that_are_not_whole_sectors(ext, oracle, R, C, ph, pw, B):
+    """Crops whose rows are not multiples of 64 bytes (PH * PW % 16 != 0), with enough ROIs for the
+    tiled path's SHIFT kernels (runs of tiles per workgroup, sector-aligned store windows, columns
+    carried from tile to tile): bit-exact like every other shape, also into a buffer that starts 4
+    bytes off a 16-byte boundary, and nothing written outside the crops."""
+    f, r = Wk.bench_inputs(R=R, C=C, H=60, W=90, img=360, seed=R + pw, batch=B)
+    r[7, 3] = 0.0               # a degenerate ROI
+    ro = r.copy()
+    r[5, 0] = float(B)          # an image index out of range: zeros (the oracle gets a valid one and a zeroed row)
+    ro[5, 0] = 0.0
+    want = oracle.forward_c(f, ro, ph, pw, 0.25, threads=8)
+    want[5] = 0.0
+    got = ext.forward(dev(f), dev(r), ph, pw, 0.25, path=ext.PATH_TILED).cpu().numpy()
+    assert mismatch(got, want)[0] == 0
+    n = want.size
+    buf = torch.full((n + 9,), float("nan"), device="cuda")
+    out = buf[1:1 + n].view(R, C, ph, pw)
+    nb = ext._lib.rroi_align_forward_workspace_bytes(B, C, 60, 90, R, ext.LAYOUT_NCHW)
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device="cuda")
+    F, Rt = dev(f), dev(r)
+    assert ext._lib.rroi_align_forward_hip(F.data_ptr(), ext.LAYOUT_NCHW, 0.25, B, R, 60, 90, C, ph, pw, Rt.data_ptr(),
+                                           out.data_ptr(), ws.data_ptr(), nb, ext.PATH_TILED,
+                                           torch.cuda.current_stream().cuda_stream) == 1
+    host = buf.cpu().numpy()
+    assert mismatch(host[1:1 + n].reshape(want.shape), want)[0] == 0
+    assert np.isnan(host[0]) and np.isnan(host[1 + n:]).all()
+
+
 @pytest.mark.parametrize("name", ["mid_c64", "batch3", "train_11xceil", "c70_odd"])
 def test_forward_channels_last_output(ext, oracle, name):
     """Crops written straight into channels_last storage: same values, element for element."""

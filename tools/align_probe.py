@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Crops whose rows are not multiples of 64 bytes (PH*PW % 16 != 0): the forward gather by store policy
+(explore build: rroi_align_debug_set_store_aux) and channel count.  us per gather launch."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import workloads as Wk
+lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_explore", "librroi_align_hip_explore.so"))
+vp, fl, it, sz = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
+lib.rroi_align_forward_stages_hip.argtypes = [vp, it, fl, it, it, it, it, it, it, it, vp, vp, vp, sz, it, it, vp]
+lib.rroi_align_forward_workspace_bytes.restype = sz
+lib.rroi_align_forward_workspace_bytes.argtypes = [it] * 6
+st = torch.cuda.current_stream().cuda_stream
+def timed(fn, warm=100, n=300):
+    for _ in range(warm): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+def case(C, ph, pw, R=512, H=160, W=160):
+    f, r = Wk.bench_inputs(R=R, C=C, H=H, W=W, img=4 * W, seed=1)
+    F, Rt = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
+    out = torch.empty((R, C, ph, pw), device="cuda")
+    nb = lib.rroi_align_forward_workspace_bytes(1, C, H, W, R, 0)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    def go(stage):
+        assert lib.rroi_align_forward_stages_hip(F.data_ptr(), 0, 0.25, 1, R, H, W, C, ph, pw, Rt.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, 2, stage, st) == 1
+    go(3)
+    res = []
+    lib.rroi_align_debug_set_fwd_shift(1, -1, -1)
+    go(3)
+    a = out.clone()
+    lib.rroi_align_debug_set_fwd_shift(0, -1, -1)
+    go(3)
+    res.append("equal" if torch.equal(a, out) else "DIFFERENT (%d)" % int((a != out).sum()))
+    for shift in (1, 0, 2):
+        lib.rroi_align_debug_set_fwd_shift(shift, -1, -1)
+        res.append(f"shift {shift}: {timed(lambda: go(2)):6.1f}")
+    lib.rroi_align_debug_set_fwd_shift(1, -1, -1)
+    if os.environ.get("RROI_ALIGN_AUX"):
+        lib.rroi_align_debug_set_fwd_shift(0, -1, -1)
+        for aux in (2, 0, 16, 3):
+            lib.rroi_align_debug_set_store_aux(aux)
+            res.append(f"aux {aux:2d}: {timed(lambda: go(2)):6.1f}")
+        lib.rroi_align_debug_set_store_aux(2)
+        lib.rroi_align_debug_set_fwd_shift(1, -1, -1)
+    print(f"R={R:4d} C={C:3d} {ph}x{pw} rows of {ph * pw * 4} B (mod 64 = {ph * pw * 4 % 64:2d}), out {R * C * ph * pw * 4 / 1e6:6.1f} MB | " + "  ".join(res))
+if os.environ.get("RROI_ALIGN_PMC"):   # a few launches of four cases for a counter pass
+    def timed(fn, warm=2, n=3):   # noqa: F811
+        for _ in range(warm + n): fn()
+        torch.cuda.synchronize()
+        return 0.0
+    case(64, 11, 96); case(64, 11, 100); case(256, 11, 96); case(256, 11, 100)
+    sys.exit(0)
+if os.environ.get("RROI_ALIGN_LEN"):
+    for ln in (0,):
+        lib.rroi_align_debug_set_fwd_shift(-1, -1, ln)
+        print("runs per block", ln or "auto")
+        for ph, pw in ((11, 83), (11, 100)):
+            for Rn in (8, 32, 128, 512, 2048):
+                case(64, ph, pw, R=Rn)
+            case(256, ph, pw, R=32); case(256, ph, pw, R=128); case(256, ph, pw, R=512)
+    sys.exit(0)
+for wgs in (-1,):
+  lib.rroi_align_debug_set_fwd_shift(-1, 0, -1)
+  print('workgroups per CU', wgs)
+  for C in (64, 256):
+    for ph, pw in ((11, 96), (11, 100), (11, 104), (8, 62), (11, 83), (11, 85), (7, 50), (3, 21)):
+        case(C, ph, pw)
