@@ -53,7 +53,7 @@ def ref_forward(lib, F, R, ph, pw, scale):
     return out, ix, iy
 
 
-@pytest.mark.parametrize("case", ["cfg2_full", "train_like", "image_like"])
+@pytest.mark.parametrize("case", ["cfg2_full", "train_like", "train_many", "image_like"])
 def test_forward_identical_to_reference_kernel(ref, case):
     from rroi_align._ext import rroi_align as ext
     if case == "cfg2_full":      # BASELINE configs[1]
@@ -61,6 +61,9 @@ def test_forward_identical_to_reference_kernel(ref, case):
         ph, pw, s = 8, 64, 0.25
     elif case == "train_like":   # src/ocr_process.py:259-267 regime
         f, r = Wk.bench_inputs(R=32, C=64, H=120, W=160, img=640, seed=5, batch=2)
+        ph, pw, s = 11, 83, 0.25
+    elif case == "train_many":   # the same pooled shape with enough ROIs for the SHIFT kernels
+        f, r = Wk.bench_inputs(R=400, C=64, H=120, W=160, img=640, seed=8, batch=2)
         ph, pw, s = 11, 83, 0.25
     else:                        # rroi_align/test2.py regime: image as the map, 44 x 349
         f, r = Wk.bench_inputs(R=3, C=3, H=276, W=500, img=500, seed=6)
