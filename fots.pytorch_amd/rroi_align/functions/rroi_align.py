@@ -16,7 +16,11 @@ from .._ext import rroi_align
 
 
 class _RRoiAlignOp(Function):
+    # Under torch.autocast the op stays what the reference is -- an fp32 operator: half / bfloat16 features are
+    # cast up on the way in (the reference's THCudaTensor signature would reject them), the crops come out fp32 and
+    # autograd casts the feature gradient back to the features' dtype.
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, features, rois, pooled_height, pooled_width, spatial_scale, channels_last_out=False):
         ctx.pooled_height = pooled_height
         ctx.pooled_width = pooled_width
@@ -30,6 +34,7 @@ class _RRoiAlignOp(Function):
                                   channels_last_out=channels_last_out)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_output):
         (rois,) = ctx.saved_tensors

@@ -601,3 +601,24 @@ def test_views_with_storage_offsets(ext, oracle):
     # a strided channel slice is made contiguous by the Python surface
     want2 = oracle.forward_c(f[:, 8:24], r, 8, 40, 0.25)
     assert eq(ext.forward(F[:, 8:24], dev(r), 8, 40, 0.25).cpu().numpy(), want2)
+
+
+def test_autograd_surface_under_autocast():
+    """torch.autocast around the module: half features are cast up on the way in, the op computes in fp32 (what the
+    reference is), the crops are the fp32 op's crops of the rounded features bit for bit, and the feature gradient
+    comes back in the features' own dtype."""
+    from rroi_align.modules.rroi_align import _RRoiAlign
+    f, r = Wk.bench_inputs(R=24, C=32, H=40, W=60, img=240, seed=77)
+    F16 = dev(f).half().requires_grad_(True)
+    R = dev(r)
+    op = _RRoiAlign(8, 32, 0.25)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = op(F16, R)
+    assert out.dtype == torch.float32
+    ref = op(F16.detach().float(), R)
+    assert torch.equal(out, ref)
+    out.pow(2).sum().backward()
+    assert F16.grad is not None and F16.grad.dtype == torch.float16 and F16.grad.shape == F16.shape
+    F32 = F16.detach().float().requires_grad_(True)
+    op(F32, R).pow(2).sum().backward()
+    assert torch.allclose(F16.grad.float(), F32.grad, rtol=2e-3, atol=1e-3 * float(F32.grad.abs().max()))
