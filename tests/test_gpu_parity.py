@@ -622,3 +622,18 @@ def test_autograd_surface_under_autocast():
     F32 = F16.detach().float().requires_grad_(True)
     op(F32, R).pow(2).sum().backward()
     assert torch.allclose(F16.grad.float(), F32.grad, rtol=2e-3, atol=1e-3 * float(F32.grad.abs().max()))
+
+
+def test_reference_launcher_on_rows_that_are_not_whole_sectors(ext):
+    """The reference-ABI forward launcher (two launches: prologue with the extra blocks for ROIs of images >= 1,
+    then the gather) takes the SHIFT kernels like the native call: same crops bit for bit, con_idx filled."""
+    f, r = Wk.bench_inputs(R=300, C=64, H=60, W=90, img=360, seed=91)
+    F, R = dev(f), dev(r)
+    want = ext.forward(F, R, 11, 83, 0.25, path=ext.PATH_TILED)
+    out, ix, iy = (torch.full((300, 64, 11, 83), float("nan"), device="cuda") for _ in range(3))
+    st = torch.cuda.current_stream().cuda_stream
+    assert ext._lib.RROIAlignForwardLaucher(F.data_ptr(), 0.25, 300, 60, 90, 64, 11, 83, R.data_ptr(), out.data_ptr(),
+                                            None, None, st) == 1
+    assert torch.equal(out, want)
+    assert ext.rroi_align_forward_cuda(11, 83, 0.25, F, R, out, ix, iy) == 1
+    assert torch.equal(out, want) and not ix.isnan().any() and not iy.isnan().any()
