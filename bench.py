@@ -16,14 +16,19 @@ Prints ONE JSON line on rank 0.
   value            ROIs/s of the whole job: K steps after W warm-up steps, wall clock between
                    barrier + synchronize on both sides, max over ranks.
   roofline         the dominant kernel (rroi_fwd_split_kernel): algorithmic bytes of one launch /
-                   its average duration over a FIXED loop of its own (300 warm-up + 500 timed
-                   back-to-back launches between two HIP events on the launch stream -- independent
-                   of --steps/--warmup; runs BEFORE the timed steps, so those start on warm clocks).
-                   `whole_call_frac` is the same bytes over `ms_per_step` (both launches).
+                   its average duration INSIDE the step (`kernel_ms.avg` = the whole call minus the
+                   prologue, each between two HIP events on the launch stream over fixed loops that
+                   do not depend on --steps/--warmup and run BEFORE the timed steps, on a chip
+                   brought up to speed).  `kernel_ms.alone` / `frac_alone`: the same kernel launched
+                   back to back by itself (300 warm-up + 500 timed).  `whole_call_frac`: the same
+                   bytes over `ms_per_step` (both launches); `whole_call_ms_spread`: median / p10 /
+                   p90 over 200 individually bracketed calls.
   cpu_baseline     the oracle (a C port of the reference's per-element semantics; the reference has
                    no runnable CPU path) timed on this host's cores -- a reported baseline, not the
                    thing measured.
-  extra            N > 1: the step followed by the RCCL all_gather of the crops into one
+  extra            `sensitivity`: the call with every bin active and with axis-aligned ROIs,
+                   next to a control run of the default draw in the same loop;
+                   N > 1: the step followed by the RCCL all_gather of the crops into one
                    preallocated (512*N, 256, 8, 64) buffer (`with_gather_ms`) and the 25 MiB all_reduce
                    of the feature gradient (`with_allreduce_grad_ms`), reported beside the kernel-only
                    step as SURVEY 8(e) asks; `ranks`: what every rank ran on (device UUID, architecture)

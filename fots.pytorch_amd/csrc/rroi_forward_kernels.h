@@ -641,6 +641,12 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
 // is a gatherer wave (phase B: tap loads, blend, transpose) and a storer wave (phase C: the stores --
 // and phase A, the geometry of the next item, which depends on no memory access and fills the time the
 // storer would otherwise idle: ~310 instructions per tile in either wave).
+// Template parameters: VEC_STORE 16-byte stores (PH * PW % 4 == 0) | AUX cache policy of the stores | EARLY LO groups
+// issued before barrier 2 | MINOR write-through stores per tile | OCC waves per SIMD (__launch_bounds__) | HID HI
+// groups single-buffered (1), double-buffered unrolled (2) or rolled (3) | ONHWC channels-last crops | SHIFT crops
+// whose rows are not whole 64-byte sectors: runs of tiles and sector-aligned store windows (1: every row a multiple
+// of 16 bytes into its sector, 2: any offset; see drain_shift).  dbg: bit 0 drops the stores, bit 1 the tap loads
+// (ablations), bit 5 the reference-ABI launcher's mode, bits 8.. SHIFT's runs per (roi, chunk) block.
 // ------------------------------------------------------------------------------------
 // Workgroup barrier that orders LDS traffic only: s_barrier does not wait for vector memory, and unlike
 // __syncthreads() nothing here makes the compiler emit s_waitcnt vmcnt(0).
