@@ -113,6 +113,7 @@ int g_waves_per_cu = 12;
 // and 12.1 KB of LDS (10 granules of 1280 B) -> 12 workgroups per CU; a larger grid would run its surplus as a second
 // round.  (Round 3's first form, <EARLY = 2, OCC = 5, HID = 2>: 90 VGPRs, 10 per CU.)
 int g_split_wgs_per_cu = 12;
+int g_shift_pre = 1;        // SHIFT: runs that start inside a block begin with a pre item (no partial sectors at cuts)
 int g_shift_parts = 0;      // exploration: > 0 forces the runs per (roi, chunk) block
 int g_shift_wgs_per_cu = 0;   // exploration: > 0 overrides the SHIFT kernels' workgroups per CU
 int g_fwd_shift = 1;  // 1: crops with PH * PW % 16 != 0 take the split kernel's SHIFT form
@@ -567,10 +568,16 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         // measured (tools/align_probe.py, 11 x 100 and 11 x 83 crops, R = 8 ... 2048, C = 64 / 256) the best cut is
         // about one run per workgroup while the ROIs are fewer than the workgroups of a chunk -- 2 for R = 512 on
         // 1280 slots (39 us; 1: 49, 3: 46, 9: 51), 6 for R = 128 on 1024 (18; 2: 32, 15: 24) -- and none beyond.
-        auto shift_parts = [&](int wgs_per_cu) {
+        // With PRE items (SHIFT = 1 only: a run that starts inside a block samples the last 16 columns of the tile
+        // before it first, stores nothing of them, and so starts on a whole sector; the run before it has nothing to
+        // flush) a cut costs a quarter of a tile's work instead of partial sectors, and six runs per block are as good
+        // as or better than the best cut without them everywhere measured (R = 2048, C = 64, 11 x 100: 124.5 against
+        // 135.5 us; R = 512: 35.7 against 38.0; profiles/r03_align_parts.txt).  The SHIFT = 2 storer is the heavier
+        // wave already: there they cost more than they save (R = 512, 11 x 83: 51 against 42 us).
+        auto shift_parts = [&](int wgs_per_cu, bool pre) {
             if (g_shift_parts > 0) return std::min(g_shift_parts, ntiles);
             const long per_roi = std::max(1L, (long)num_cus() * wgs_per_cu / nchunks) / std::max(1, num_rois);
-            long m = per_roi <= 3 ? per_roi : 3 * per_roi / 4;
+            long m = pre ? std::max(6L, 3 * per_roi / 4) : per_roi <= 3 ? per_roi : 3 * per_roi / 4;
             m = std::max(1L, std::min<long>(m, ntiles));
             while (m > 1 && (m - 1) * ceil_div(ntiles, (int)m) >= ntiles) --m;   // no empty last part
             return (int)m;
@@ -618,11 +625,13 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
 #define RROI_LAUNCH_SHIFT(S, O, W)                                                                            \
     do {                                                                                                      \
         const int wpc = g_shift_wgs_per_cu > 0 ? g_shift_wgs_per_cu : W;                                      \
-        const int sp = shift_parts(wpc);                                                                      \
+        const bool pre = g_shift_pre && S == 1;                                                               \
+        const int sp = shift_parts(wpc, pre);                                                                 \
         hipLaunchKernelGGL((rroi_fwd_split_kernel<true, 2, 0, 1, O, 3, false, S>),                            \
                            dim3(tiled_grid((long)num_rois * sp, nchunks, wpc)), dim3(2 * kWave), 0, stream, map, \
                            ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,   \
-                           nchunks, ntiles, lay, dt, dp, (g_fwd_dbg & 255) | (launcher_rest ? 32 : 0) | (sp << 8)); \
+                           nchunks, ntiles, lay, dt, dp,                                                        \
+                           (g_fwd_dbg & 31) | (launcher_rest ? 32 : 0) | (sp > 1 && pre ? 64 : 0) | (sp << 8)); \
     } while (0)
         else if ((g_fwd_split || launcher_rest) && g_store_aux == 2 && (NB % 16 != 0 || g_fwd_shift == 2) && g_fwd_shift && shift_pays) {
             // 1: every row starts a multiple of 16 bytes into its sector; 2: any offset
@@ -690,7 +699,8 @@ int rroi_align_debug_set_fwd_shift(int v, int wgs_per_cu, int parts)
     const int old = g_fwd_shift;
     if (v >= 0) g_fwd_shift = v;
     if (wgs_per_cu >= 0) g_shift_wgs_per_cu = wgs_per_cu;
-    if (parts >= 0) g_shift_parts = parts;
+    if (parts >= 0) g_shift_parts = parts & 255;
+    if (parts >= 0) g_shift_pre = (parts & 256) ? 0 : 1;   // + 256: without the pre items
     return old;
 }
 int rroi_align_debug_set_bwd_buckets(int v)

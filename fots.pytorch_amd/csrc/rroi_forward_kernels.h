@@ -726,7 +726,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // Offsets are byte offsets into the slice; kOOB reads as 0.0, which is what
     // kernel.cu:116-126 substitutes for a tap outside the map.
     auto geometry = [&](const Affine& A, unsigned t, unsigned p, unsigned& n_lo_groups,
-                        unsigned& n_hi_groups, unsigned long long& amask) {
+                        unsigned& n_hi_groups, unsigned long long& amask, unsigned min_lane = 0u) {
         uint4* const G = Gbuf + p * kRecs;
         unsigned char* const HP = HPbuf + p * kRecs;
         const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         const unsigned pw = bin - ph * (unsigned)pooled_width;
         float bcx, bcy;
         bool active = bin_centre(A, (int)ph, (int)pw, height, width, bcx, bcy);
-        active = active && bin < (unsigned)NB && batch_ok;
+        active = active && bin < (unsigned)NB && batch_ok && lane >= min_lane;
         const float fx = floorf(bcx), fy = floorf(bcy);
         const int x0 = f2i_sat(fx), x1 = f2i_sat(ceilf(bcx));
         const int y0 = f2i_sat(fy), y1 = f2i_sat(ceilf(bcy));
@@ -1075,17 +1075,24 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     const unsigned parts = SHIFT ? max(1u, (unsigned)dbg >> 8) : 1u;
     const unsigned len = (ntiles + parts - 1u) / parts;
     unsigned run = slot, run_end = 0;   // SHIFT: the current run and one past its last item
+    // dbg & 64: a run that starts inside a block begins one tile EARLY with a "pre" item -- only that tile's last 16
+    // columns are sampled and nothing of it is stored: it fills the carried groups, so that the run's first window
+    // starts on a whole sector like every other and the run before it has nothing to flush (no partial sectors at cuts)
+    const bool pre_tiles = SHIFT && (dbg & 64);
+    bool cur_pre = false;
     auto enter_run = [&]() -> unsigned {   // first item of run `run` (kEnd beyond the last run); empty parts are skipped
         for (;; run += nslots) {
             if (run >= (unsigned)num_rois * parts) return kEnd;
             const unsigned rn = run / parts, part = run - rn * parts;
             if (part * len >= (unsigned)ntiles) continue;
             run_end = rn * (unsigned)ntiles + min((unsigned)ntiles, (part + 1u) * len);
-            return rn * (unsigned)ntiles + part * len;
+            cur_pre = pre_tiles && part > 0u;
+            return rn * (unsigned)ntiles + part * len - (cur_pre ? 1u : 0u);
         }
     };
     auto next = [&](unsigned c) -> unsigned {
         if (!SHIFT) return c + nslots < items ? c + nslots : kEnd;
+        cur_pre = false;
         if (c + 1u < run_end) return c + 1u;
         run += nslots;
         return enter_run();
@@ -1102,20 +1109,25 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         // written by the prologue launch -- they are not zero-filled here
         bool skip_cur = false, skip_prev = false;
         bool carry_prev = false;   // SHIFT: the tile before `prev` was its left neighbour, stored by this workgroup
+        bool pre_prev = false;     // SHIFT: `prev` is a pre item (sampled for its last columns, not stored)
         auto plan = [&](unsigned pn, unsigned pt, unsigned pp, unsigned long long& m) {
             const Affine A = aff[pn];
             skip_cur = (dbg & 32) && A.batch >= batch_size;  // (a negative index still yields zeros)
-            geometry(A, pt, pp, gl, gh, m);
+            geometry(A, pt, pp, gl, gh, m, cur_pre ? 48u : 0u);
             if (lane == 0) shead[pp] = make_uint4(gl, gh, (unsigned)m, (unsigned)(m >> 32));
         };
+        bool pre_cur = cur_pre;
         plan(n, t, 0, mask_cur);
         for (bool have_prev = false;; have_prev = true) {
             wg_lds_barrier();  // 1: records of item `cur` are in set p; the tile of the previous item is in T
             if (have_prev) {
                 if (SHIFT) {
                     // the run ends with `prev` (runs do not cross into the next roi's block)
-                    const bool last = cur != n_prev * (unsigned)ntiles + t_prev + 1u || t_prev + 1u == (unsigned)ntiles;
-                    drain_shift(n_prev, t_prev, mask_prev, skip_prev, carry_prev, last);
+                    const bool row_end = t_prev + 1u == (unsigned)ntiles;
+                    const bool last = cur != n_prev * (unsigned)ntiles + t_prev + 1u || row_end;
+                    // with pre items the run that follows writes the sector the two runs share
+                    drain_shift(n_prev, t_prev, mask_prev, skip_prev || pre_prev, carry_prev && !pre_prev,
+                                pre_tiles ? row_end : last);
                     carry_prev = !last;
                 } else {
                     drain_tile(n_prev, t_prev, mask_prev, skip_prev);  // T -> registers | barrier 2 | stores
@@ -1128,7 +1140,9 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             t_prev = t;
             mask_prev = mask_cur;
             skip_prev = skip_cur;
+            pre_prev = pre_cur;
             cur = next(cur);
+            pre_cur = cur_pre;
             if (cur != kEnd) {
                 n = fdiv(cur, div_tiles);
                 t = cur - n * (unsigned)ntiles;
