@@ -59,6 +59,8 @@ def main():
     rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 11)
     ref = load_ref()
     ph, pw, s, H, W = 8, 64, 0.25, 160, 160
+    if os.environ.get("RROI_FUZZ_POOLED"):   # e.g. 11x83: rows that are not whole sectors (the SHIFT kernels)
+        ph, pw = (int(v) for v in os.environ["RROI_FUZZ_POOLED"].split("x"))
     F = torch.from_numpy(rng.standard_normal((1, 1, H, W), dtype=np.float32)).cuda()
     tot = dict(rois=0, bins=0, bins_centre_differs=0, rois_centre_differs=0, out_differs_tiled=0,
                out_differs_direct=0, out_differs_where_centres_agree=0, max_centre_shift=0.0)
@@ -88,6 +90,7 @@ def main():
         for i in torch.nonzero(per_roi).flatten()[:4].tolist():
             worst.append([float(v) for v in r[i]] + [int(dxy[i].sum())])
     tot["differing_bins_per_million"] = round(1e6 * tot["bins_centre_differs"] / max(1, tot["bins"]), 3)
+    tot["pooled"] = [ph, pw]
     tot["example_rois"] = worst[:8]
     print(json.dumps(tot))
 
