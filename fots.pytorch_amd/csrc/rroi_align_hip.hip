@@ -397,7 +397,7 @@ void* launcher_scratch(hipStream_t stream, size_t bytes, bool* transient, hipErr
 // ====================================================================================
 extern "C" {
 
-const char* rroi_align_hip_version(void) { return "rroi_align_hip 0.5.0 gfx950"; }
+const char* rroi_align_hip_version(void) { return "rroi_align_hip 0.6.0 gfx950"; }
 
 size_t rroi_align_forward_workspace_bytes(int batch_size, int channels, int height, int width,
                                           int num_rois, int feature_layout)
