@@ -534,6 +534,24 @@ __global__ __launch_bounds__(256) void rroi_cm_to_nchw_kernel(const float* __res
     }
     __syncthreads();
     float* dst = nchw + ((size_t)b * C + c0) * HW + p0;
+    // rows of 16-byte aligned float4 (p0 is a multiple of 128): four 16-byte stores per thread instead of sixteen
+    // dwords -- a wave instruction writes two 512-byte runs (the prologue's read mapping, mirrored)
+    if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(nchw) & 15) == 0) {
+        const int x4 = lane & 31, csub = lane >> 5;
+        const int p = 4 * x4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = w * 8 + i * 2 + csub;
+            if (c0 + c < C && p0 + p < HW) {   // HW % 4 == 0: the four pixels are inside together
+                const float* tr = T + c * (kRelayoutPx + 1) + p;
+                v4f v = {tr[0], tr[1], tr[2], tr[3]};
+                v4f* o = reinterpret_cast<v4f*>(dst + (size_t)c * HW + p);
+                if (ACCUM) v += *o;
+                *o = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = w * 8 + i;
