@@ -134,3 +134,16 @@ def test_product_never_imports_the_oracle():
             checked += 1
             assert not bad.search(open(path, errors="ignore").read()), path
     assert checked >= 6
+
+
+def test_python_constants_are_the_headers():
+    """PATH_* / LAYOUT_* of the ctypes binding are the #defines of include/rroi_align_hip.h, value for value."""
+    import re
+    from rroi_align._ext import rroi_align as ext
+    text = open(os.path.join(ROOT, "include", "rroi_align_hip.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+RROI_((?:PATH|LAYOUT)_\w+)\s+(\d+)", text)}
+    assert len(defs) >= 9
+    for name, value in defs.items():
+        assert getattr(ext, name) == value, name
+    assert set(ext.BACKWARD_PATHS) == {v for k, v in defs.items() if k.startswith("PATH_")}
+    assert set(ext.FORWARD_PATHS) <= set(ext.BACKWARD_PATHS)
