@@ -26,6 +26,7 @@
 // recipe, descriptor helpers), rroi_forward_kernels.h, rroi_backward_kernels.h,
 // rroi_callers_kernels.h, rroi_nms_kernels.h (+ rroi_nms_host.h, host C++).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <math.h>
@@ -117,6 +118,8 @@ int g_shift_pre = 1;        // SHIFT: runs that start inside a block begin with 
 int g_shift_parts = 0;      // exploration: > 0 forces the runs per (roi, chunk) block
 int g_shift_wgs_per_cu = 0;   // exploration: > 0 overrides the SHIFT kernels' workgroups per CU
 int g_fwd_shift = 1;  // 1: crops with PH * PW % 16 != 0 take the split kernel's SHIFT form
+int g_fwd_dyn_tail = 1;  // the strided items a slot would get beyond items / slots are claimed (round 4)
+int g_fwd_anyorder = 0;  // EXPERIMENT (round 4): the gather's AQL packet without the barrier bit
 int g_fwd_split = 1;  // 1: loads and stores in different waves (rroi_fwd_split_kernel) for NCHW crops
 
 int tiled_grid(long items, int nchunks, int per_cu = 0)
@@ -172,6 +175,7 @@ PatchMap make_patch_map(int pooled_height, int pooled_width)
 
 struct Workspace {
     Affine* aff;
+    unsigned* tail;   // 8 x kTailShards counters of the gather's dynamic tail (cleared by every prologue)
     float* cm;
     size_t cm_bytes;
     size_t bytes;
@@ -183,8 +187,9 @@ Workspace carve(void* ws, int batch_size, int channels, int height, int width, i
                 int layout)
 {
     Workspace w;
-    const size_t aff_bytes = align_up((size_t)(num_rois > 0 ? num_rois : 1) * sizeof(Affine), 256);
+    const size_t aff_bytes = align_up((size_t)(num_rois > 0 ? num_rois : 1) * sizeof(Affine), 256) + 512;
     const size_t nchunks = (channels + kChunk - 1) / kChunk;
+    w.tail = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + aff_bytes - 512);
     w.cm_bytes = layout == RROI_LAYOUT_NHWC
                      ? 0
                      : align_up((size_t)batch_size * nchunks * ((size_t)height * row_pitch(width) + 1) * kLineBytes, 256);
@@ -510,7 +515,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     const float* map = zero_copy ? features : ws.cm;
     const int pitch = row_pitch(width);
 
-    // prologue: relayout + zero pixels + affine table in one launch
+    // prologue: relayout + affine table in one launch
     if (stages & RROI_STAGE_PROLOGUE) {
         const int ptiles = ceil_div(HW, kRelayoutPx);
         const int relayout_tiles = zero_copy ? 0 : ptiles * nchunks * batch_size;
@@ -522,17 +527,16 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
             while (unit % 8) unit += nchunks;  // lcm(nchunks, 8): keeps block -> chunk -> XCD stable
             if (relayout_blocks >= unit) relayout_blocks = (int)(relayout_blocks / unit * unit);
         }
-        const int zero_blocks = zero_copy ? 0 : ceil_div((long)batch_size * nchunks * kChunk, 256);
         const int aff_blocks = ceil_div(num_rois, 256);
         const int rest_blocks = launcher_rest ? num_rois : 0;
 #define RROI_LAUNCH_PRO(AUX)                                                                        \
     hipLaunchKernelGGL(rroi_prologue_kernel<AUX>,                                                     \
-                       dim3(relayout_blocks + zero_blocks + aff_blocks + rest_blocks), dim3(256), 0,  \
+                       dim3(relayout_blocks + aff_blocks + rest_blocks), dim3(256), 0,               \
                        stream, features, ws.cm, channels, HW, width, pitch,                           \
                        make_fastdiv((unsigned)width), nchunks, ptiles, relayout_blocks,               \
-                       relayout_tiles, zero_blocks, batch_size, rois, num_rois, pooled_height,        \
+                       relayout_tiles, batch_size, rois, num_rois, pooled_height,                     \
                        spatial_scale, ws.aff, aff_blocks, launcher_rest ? top_data : (float*)nullptr, \
-                       pooled_width)
+                       pooled_width, ws.tail)
         if (g_prologue_aux == 16) RROI_LAUNCH_PRO(16);
         else RROI_LAUNCH_PRO(0);
 #undef RROI_LAUNCH_PRO
@@ -592,10 +596,14 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         // to four interleaved rounds): as fast as <2, 1, 5, 2> with 10 per CU on the default draw (step 53.5-53.75
         // against 53.45-53.85 us, gather alone 44.5-44.9 against 45.5-46.1) and faster where the gatherer waves are the
         // critical path -- every bin active (w = 8 h): step 55.4-55.9 against 57.0-57.3 us
+        // dynamic tail: needs the counters the prologue clears (not with channels-last features consumed in place: no
+        // prologue relayout, but the affine blocks run there too) and at most 8 chunk counters ... at least 4 items per slot
+        const bool dyn_tail = g_fwd_dyn_tail && (stages & RROI_STAGE_PROLOGUE) && !zero_copy && nchunks <= 8 && (long)num_rois * ntiles / std::max(1, sgrid / nchunks) >= 4;
 #define RROI_LAUNCH_SPLIT(VEC)                                                                           \
-    hipLaunchKernelGGL((rroi_fwd_split_kernel<VEC, 2, 0, 1, 6, 3>), dim3(sgrid), dim3(2 * kWave), 0, stream, map, \
+    hipExtLaunchKernelGGL((rroi_fwd_split_kernel<VEC, 2, 0, 1, 6, 3>), dim3(sgrid), dim3(2 * kWave), 0, stream, nullptr, nullptr, \
+                       g_fwd_anyorder ? hipExtAnyOrderLaunch : 0, map, \
                        ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size, \
-                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg | (launcher_rest ? 32 : 0))
+                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg | (launcher_rest ? 32 : 0) | (dyn_tail ? 128 : 0), ws.tail)
         // channels-last crops: the split kernel behind the prologue (55.2 against 56.4-58.6 us at cfg2); with
         // channels-last features consumed in place the one-wave kernel is as fast or faster (51.6 against 52.3)
         if (out_nhwc && !zero_copy && g_fwd_split && g_store_aux == 2)
@@ -701,6 +709,22 @@ int rroi_align_debug_set_fwd_shift(int v, int wgs_per_cu, int parts)
     if (wgs_per_cu >= 0) g_shift_wgs_per_cu = wgs_per_cu;
     if (parts >= 0) g_shift_parts = parts & 255;
     if (parts >= 0) g_shift_pre = (parts & 256) ? 0 : 1;   // + 256: without the pre items
+    return old;
+}
+int rroi_align_debug_set_wg_trace(unsigned* device_buffer)
+{
+    return status_of(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace), &device_buffer, sizeof(device_buffer)));
+}
+int rroi_align_debug_set_fwd_dyn_tail(int v)
+{
+    const int old = g_fwd_dyn_tail;
+    g_fwd_dyn_tail = v;
+    return old;
+}
+int rroi_align_debug_set_fwd_anyorder(int v)
+{
+    const int old = g_fwd_anyorder;
+    g_fwd_anyorder = v;
     return old;
 }
 int rroi_align_debug_set_bwd_buckets(int v)
@@ -1103,11 +1127,11 @@ int rroi_rbox_decode_hip(const float* segm, const float* rbox, const float* angl
     const int hw = height * width;
     const int slabs = ceil_div(hw, 1024);
     unsigned* slab_counts = nullptr;
-    if (slabs > 256) {
-        // large map: per-slab counts from a first launch, kept behind the records the caller's buffer holds
-        // (capacity * 64 bytes are the caller's; the counts need room of their own: the tail of the records
-        // beyond what can ever be used -- a map of hw pixels yields at most hw records)
-        if ((long)capacity < (long)hw + ceil_div((long)slabs * 4, 64)) return 0;
+    // large map: per-slab counts from a first launch, kept behind the records the caller's buffer can ever
+    // need (a map of hw pixels yields at most hw records) -- when the buffer has that room.  A buffer sized
+    // for fewer records (a caller relying on *count to report the overflow, or one sized to exactly h * w)
+    // keeps the one-launch form, in which every workgroup counts the pixels before its slab itself.
+    if (slabs > 256 && (long)capacity >= (long)hw + ceil_div((long)slabs * 4, 64)) {
         slab_counts = reinterpret_cast<unsigned*>(static_cast<NmsCandidate*>(candidates) + hw);
         hipLaunchKernelGGL(rroi_rbox_count_kernel, dim3(slabs), dim3(1024), 0, stream, segm, hw, segm_thresh, slab_counts);
         const int st = launch_status();

@@ -9,10 +9,12 @@
 //   blocks [0, relayout_blocks)      NCHW -> chunk-major: a [32 ch] x [128 px] tile goes
 //                                    through LDS; reads are 512 B runs of a channel row,
 //                                    writes are one contiguous 16 KiB run of the slice;
-//   then zero_blocks                 the zero pixel that ends every slice;
-//   then the rest                    per-ROI affine table (R x 32 B).
+//   then the rest                    per-ROI affine table (R x 32 B) (+ the gather's tail counters cleared).
+// (Every slice of the copy still ENDS in one spare pixel -- rounds 1-3 kept a zero pixel there for invalid taps;
+// they have pointed at out-of-range descriptor offsets since round 1 and nothing reads it, so nothing writes it.)
 // ------------------------------------------------------------------------------------
 constexpr int kRelayoutPx = 128;
+constexpr unsigned kTailShards = 16;   // claim counters per channel chunk (dynamic tail of the split gather)
 
 // The relayout proper, shared by the forward prologue (feature map) and the backward (top_diff,
 // R "images" of PH x PW "pixels").  MASK: image b is ROI b and pixels (ph, pw) with
@@ -197,19 +199,19 @@ __device__ __forceinline__ void direct_bin(const float* __restrict__ feat, const
 template <int AUX>
 __global__ __launch_bounds__(256) void rroi_prologue_kernel(
     const float* __restrict__ nchw, float* __restrict__ cm, int C, int HW, int width, int pitch,
-    FastDiv div_w, int nchunks, int ptiles, int relayout_blocks, int relayout_tiles, int zero_blocks,
+    FastDiv div_w, int nchunks, int ptiles, int relayout_blocks, int relayout_tiles,
     int batch_size, const float* __restrict__ rois, int num_rois, int pooled_height,
     float spatial_scale, Affine* __restrict__ aff, int aff_blocks = 0, float* __restrict__ rest_out = nullptr,
-    int pooled_width = 0)
+    int pooled_width = 0, unsigned* __restrict__ tail_cnt = nullptr)
 {
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
     const int tid = threadIdx.x;
-    if (rest_out && (int)blockIdx.x >= relayout_blocks + zero_blocks + aff_blocks) {
+    if (rest_out && (int)blockIdx.x >= relayout_blocks + aff_blocks) {
         // The reference-ABI launcher (one more block per ROI).  Its signature does not say how many images
         // `nchw` holds, so the copy and the tiled gather serve image 0; the ROIs of images >= 1 -- none, as a
         // rule: the block reads the index and leaves -- are sampled here from the NCHW tensor, trusting the
         // index as the reference does, and the gather leaves their crops alone.
-        const int n = (int)blockIdx.x - relayout_blocks - zero_blocks - aff_blocks;
+        const int n = (int)blockIdx.x - relayout_blocks - aff_blocks;
         if (f2i_sat(rois[(size_t)n * 6]) < batch_size) return;
         const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
         const int NB = pooled_height * pooled_width;
@@ -217,17 +219,10 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
             direct_bin(nchw, A, rest_out, nullptr, nullptr, n, bin, C, HW / width, width, pooled_width, NB, /*trust*/ -1, 0, C);
         return;
     }
-    if ((int)blockIdx.x >= relayout_blocks + zero_blocks) {
-        const int n = ((int)blockIdx.x - relayout_blocks - zero_blocks) * 256 + tid;
-        if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
-        return;
-    }
     if ((int)blockIdx.x >= relayout_blocks) {
-        const size_t zp_index = (size_t)(HW / width) * pitch;  // pixel index of the zero pixel
-        const size_t slice_stride = (zp_index + 1) * kChunk;
-        const int i = ((int)blockIdx.x - relayout_blocks) * 256 + tid;  // (slice, channel-in-chunk)
-        if (i < batch_size * nchunks * kChunk)
-            cm[(size_t)(i / kChunk) * slice_stride + zp_index * kChunk + (i % kChunk)] = 0.0f;
+        const int n = ((int)blockIdx.x - relayout_blocks) * 256 + tid;
+        if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+        if (tail_cnt && n < 8 * kTailShards) tail_cnt[n] = 0u;   // the gather's dynamic-tail counters (rroi_fwd_split_kernel)
         return;
     }
     relayout_run<AUX, false>(T, nchw, cm, C, HW, width, pitch, div_w, nchunks, ptiles, (int)blockIdx.x,
@@ -652,12 +647,24 @@ __global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
 // __syncthreads() nothing here makes the compiler emit s_waitcnt vmcnt(0).
 __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifdef RROI_EXPLORE
+// exploration: per-workgroup time stamps of the split kernel (100 MHz s_memrealtime, low 32 bits):
+// [8 b + 0] storer entry, + 1 the gatherer's first loads, + 2 the storer's first store, + 3 storer exit,
+// + 4 HW_REG_HW_ID, + 5 HW_REG_XCC_ID, + 6 the time half of the items were drained, + 7 items drained
+__device__ unsigned* g_wg_trace = nullptr;
+#define RROI_TRACE(i) do { if (g_wg_trace && lane == 0) g_wg_trace[8u * blockIdx.x + (i)] = (unsigned)wall_clock64(); } while (0)
+#define RROI_TRACE_V(i, v) do { if (g_wg_trace && lane == 0) g_wg_trace[8u * blockIdx.x + (i)] = (v); } while (0)
+#else
+#define RROI_TRACE(i) do { } while (0)
+#endif
+
 template <bool VEC_STORE, int AUX, int EARLY = 2, int MINOR = 1, int OCC = 5, int HID = 2, bool ONHWC = false,
           int SHIFT = 0>
 __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
-    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg)
+    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg,
+    unsigned* __restrict__ tail_cnt = nullptr)
 {
     // A tile's bins are processed in CLASS-SORTED groups of 8, because the texture addresser
     // charges 16 cycles for every dwordx4 wave instruction whatever the number of lanes that
@@ -692,6 +699,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     __shared__ __attribute__((aligned(16))) uint4 Gbuf[2 * kRecs];
     __shared__ unsigned char HPbuf[2 * kRecs];
     __shared__ uint4 shead[2];  // per record set: LO groups, HI groups, mask of the bins that are in a group
+    __shared__ unsigned sclaim; // dynamic tail: the item the gatherer claimed for this workgroup (kEnd: none)
 
     const unsigned lane = threadIdx.x & 63u;
     // wave 0 gathers (loads only), wave 1 streams the finished tiles out (stores only)
@@ -1090,8 +1098,26 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             return rn * (unsigned)ntiles + part * len - (cur_pre ? 1u : 0u);
         }
     };
+    // Dynamic tail (dbg & 128, strided items only; round 4).  Every workgroup takes its J = items / nslots strided
+    // items as before; the items - J * nslots left over (fewer than nslots) are not dealt to the first slots but
+    // CLAIMED, first come first served: per-workgroup time stamps showed that the workgroups' progress differs by
+    // up to 9 us from the launch's first microseconds on (the first tiles of 3072 workgroups are gathered at once)
+    // and stays that way, so the workgroups that are ahead should be the ones that take an eleventh item.
+    // Same-address atomics serialise (tens of ns each): the pool of a chunk is dealt to kTailShards counters, slot s
+    // claims from shard s % kTailShards, whose items are static_end + shard + r * kTailShards.  The gatherer issues
+    // the claim at the end of static item J - 3 -- two items before the answer is needed, no load in flight at that
+    // point -- reads it at the end of item J - 2 and hands it to the storer through LDS before barrier 1 of item
+    // J - 1.  tail_cnt[k * kTailShards + shard] is cleared by the prologue launch of the same call.
+    const unsigned J = items / nslots;
+    const bool dyn = !SHIFT && (dbg & 128) && J >= 4u;
+    const unsigned static_end = dyn ? J * nslots : items;
+    unsigned claimed = kEnd;   // (the gatherer's copy; the storer reads sclaim)
     auto next = [&](unsigned c) -> unsigned {
-        if (!SHIFT) return c + nslots < items ? c + nslots : kEnd;
+        if (!SHIFT) {
+            if (c + nslots < static_end) return c + nslots;
+            // behind the last static item: the claimed one, if any; behind that, nothing
+            return (dyn && c < static_end) ? (storer ? sclaim : claimed) : kEnd;
+        }
         cur_pre = false;
         if (c + 1u < run_end) return c + 1u;
         run += nslots;
@@ -1100,6 +1126,17 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     unsigned cur = SHIFT ? enter_run() : (slot < items ? slot : kEnd);
     if (cur == kEnd) return;
     if (storer) {
+        RROI_TRACE(0);
+#ifdef RROI_EXPLORE
+        {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            RROI_TRACE_V(4, hw);
+            RROI_TRACE_V(5, xcc);
+        }
+        unsigned drained = 0;
+#endif
         unsigned n = fdiv(cur, div_tiles), t = cur - n * (unsigned)ntiles;
         unsigned p = 0;
         unsigned gl, gh;
@@ -1110,13 +1147,26 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         bool skip_cur = false, skip_prev = false;
         bool carry_prev = false;   // SHIFT: the tile before `prev` was its left neighbour, stored by this workgroup
         bool pre_prev = false;     // SHIFT: `prev` is a pre item (sampled for its last columns, not stored)
+#ifdef RROI_EXPLORE
+        bool first_plan = true;
+#endif
         auto plan = [&](unsigned pn, unsigned pt, unsigned pp, unsigned long long& m) {
             const Affine A = aff[pn];
             skip_cur = (dbg & 32) && A.batch >= batch_size;  // (a negative index still yields zeros)
+#ifdef RROI_EXPLORE
+            // ablation (dbg & 256): the workgroup's FIRST item costs nothing -- no geometry, no taps (its tile is zeros):
+            // an upper bound on what any shortening of the launch's start-up chain can gain
+            geometry(A, pt, pp, gl, gh, m, ((dbg & 256) && first_plan) ? 64u : cur_pre ? 48u : 0u);
+            first_plan = false;
+#else
             geometry(A, pt, pp, gl, gh, m, cur_pre ? 48u : 0u);
+#endif
             if (lane == 0) shead[pp] = make_uint4(gl, gh, (unsigned)m, (unsigned)(m >> 32));
         };
         bool pre_cur = cur_pre;
+#ifdef RROI_EXPLORE
+        bool traced_first = false;
+#endif
         plan(n, t, 0, mask_cur);
         for (bool have_prev = false;; have_prev = true) {
             wg_lds_barrier();  // 1: records of item `cur` are in set p; the tile of the previous item is in T
@@ -1132,6 +1182,11 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                 } else {
                     drain_tile(n_prev, t_prev, mask_prev, skip_prev);  // T -> registers | barrier 2 | stores
                 }
+#ifdef RROI_EXPLORE
+                if (!traced_first) { RROI_TRACE(2); traced_first = true; }
+                if (++drained == 5) RROI_TRACE(6);
+                RROI_TRACE_V(7, drained);
+#endif
             } else {
                 wg_lds_barrier();
             }
@@ -1150,12 +1205,15 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                 plan(n, t, p, mask_cur);  // while the gatherer blends the item before
             }
         }
+        RROI_TRACE(3);
         return;
     }
     // the gatherer's chain (records -> loads -> blend) is the latency of a tile; the storer's geometry is
     // not urgent: with the gatherer ahead in the issue arbitration the call is 0.7 us shorter (any level > 0)
     __builtin_amdgcn_s_setprio(2);
     unsigned p = 0;
+    unsigned claim_raw = 0;
+    const unsigned claim_at = slot + (J - 3u) * nslots, read_at = slot + (J - 2u) * nslots;
     for (;; cur = next(cur), p ^= 1u) {
         wg_lds_barrier();  // 1: the storer has put this item's records into set p (and our previous tile is complete)
         if (cur == kEnd) {
@@ -1181,6 +1239,9 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         }
         fetch_lo(p, kEarly, 0);
         issue_lo(rs, 0);
+#ifdef RROI_EXPLORE
+        if (cur == (SHIFT ? cur : slot)) RROI_TRACE(1);
+#endif
         wg_lds_barrier();  // 2: the storer holds the previous tile in registers: T is free
 
         // ---- phase B: the loads of group g+1 are issued before group g is blended.  The loops are
@@ -1260,6 +1321,17 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                     asm volatile("; hi: last group");
                     break;
                 }
+            }
+        }
+        if (dyn) {
+            // (no tap load is in flight here: the claim's round trip runs under item J - 2)
+            const unsigned shard = slot % kTailShards;
+            if (cur == claim_at && lane == 0) claim_raw = atomicAdd(tail_cnt + k * kTailShards + shard, 1u);
+            if (cur == read_at) {
+                const unsigned r = (unsigned)__builtin_amdgcn_readfirstlane((int)claim_raw);
+                const unsigned item = static_end + shard + r * kTailShards;
+                claimed = (r < nslots && item < items) ? item : kEnd;
+                if (lane == 0) sclaim = claimed;   // read by the storer behind barrier 1 of item J - 1
             }
         }
     }

@@ -243,7 +243,19 @@ inline std::vector<NmsPoly> nms_merge(const NmsCandidate* cand, int n, int w, in
             poly.Y[v] = cand[i].quad[2 * v + 1];
         }
         poly.score = cand[i].score;
-        for (int v = 0; v < 4; ++v) poly.probs[v] = cand[i].probs[v];
+        {
+            // adaptor.cpp:94-100, 107: ph = phx = 9; the C library's expf, as the reference calls it
+            const float* r = cand[i].rdist;
+            const float ph = 9, phx = 9;
+            const float p_left = expf(-r[2] / phx);
+            const float p_top = expf(-r[0] / ph);
+            const float p_right = expf(-r[3] / phx);
+            const float p_bt = expf(-r[1] / ph);
+            poly.probs[0] = p_left * p_bt;
+            poly.probs[1] = p_left * p_top;
+            poly.probs[2] = p_right * p_top;
+            poly.probs[3] = p_right * p_bt;
+        }
         poly.x = cand[i].x;
         poly.y = cand[i].y;
         const size_t here = (size_t)poly.y * w + poly.x;

@@ -18,14 +18,16 @@
 // 176 x 320 map of a 1280 x 704 image in 14 steps, out of L2 -- so there is no second launch, no flag
 // chain between workgroups and no counter that somebody would have to clear.  (Maps beyond 256 K pixels,
 // where the redundant counting would cost more than a launch, take per-slab counts from a first launch.)
-// fp32 arithmetic exactly as adaptor.cpp writes it (-ffp-contract=off); the corner confidences
-// use exp in double rounded once, the C library's expf the reference calls agrees with that except
-// for an occasional last place (the quads do not depend on it).
+// fp32 arithmetic exactly as adaptor.cpp writes it (-ffp-contract=off).  The corner confidences
+// (adaptor.cpp:97-100, 107: products of expf(-r / 9)) are NOT formed here: the record carries the four raw
+// RBOX distances and the host merge, which consumes them, calls the same C library expf the reference calls
+// (round 4; rounds 2-3 evaluated exp in double on the device, <= 2 ulp off the library's expf).
 // ------------------------------------------------------------------------------------
 struct NmsCandidate {  // 64 bytes
     int quad[8];       // x0,y0 .. x3,y3 in 1/10000 px (adaptor.cpp:101-104)
     float score;
-    float probs[4];    // p_left*p_bt, p_left*p_top, p_right*p_top, p_right*p_bt (:107)
+    float rdist[4];    // r[0..3] = distances to the top, bottom, left, right edge (:79); the confidences
+                       // p_left*p_bt, p_left*p_top, p_right*p_top, p_right*p_bt (:97-100, 107) are formed on the host
     int x, y;
     int pad;
 };
@@ -104,8 +106,6 @@ __global__ __launch_bounds__(1024) void rroi_rbox_decode_kernel(
             const float pos_r_y = (yp - r2 * angle_sin) * scale_factor;
             const float pos_r2_x = (xp + r3 * angle_cos) * scale_factor;
             const float pos_r2_y = (yp + r3 * angle_sin) * scale_factor;
-            const float p_left = (float)exp((double)(-r2 / 9.0f)), p_top = (float)exp((double)(-r0 / 9.0f));
-            const float p_right = (float)exp((double)(-r3 / 9.0f)), p_bt = (float)exp((double)(-r1 / 9.0f));
             NmsCandidate c;
             c.quad[0] = (int)roundf(precision * (pos_r_x - r1 * angle_sin * scale_factor));
             c.quad[1] = (int)roundf(precision * (pos_r_y + r1 * angle_cos * scale_factor));
@@ -116,10 +116,10 @@ __global__ __launch_bounds__(1024) void rroi_rbox_decode_kernel(
             c.quad[6] = (int)roundf(precision * (pos_r2_x - r1 * angle_sin * scale_factor));
             c.quad[7] = (int)roundf(precision * (pos_r2_y + r1 * angle_cos * scale_factor));
             c.score = segm[p];
-            c.probs[0] = p_left * p_bt;
-            c.probs[1] = p_left * p_top;
-            c.probs[2] = p_right * p_top;
-            c.probs[3] = p_right * p_bt;
+            c.rdist[0] = r0;
+            c.rdist[1] = r1;
+            c.rdist[2] = r2;
+            c.rdist[3] = r3;
             c.x = x;
             c.y = y;
             c.pad = 0;

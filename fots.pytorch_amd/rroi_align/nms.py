@@ -3,7 +3,7 @@ reference): score / RBOX / angle maps -> merged word quads, the input of ROI con
 
 The reference pulls the three full-resolution maps to the host, transposes them with numpy and
 runs everything in C++ on the CPU (test.py:86-96, nms/adaptor.cpp, nms/nms.h).  Here the per-pixel
-half -- threshold, RBOX -> quad decode, corner confidences -- is a HIP kernel on the maps where the
+half -- threshold, RBOX -> quad decode -- is a HIP kernel on the maps where the
 network wrote them (channels-first, no transposes), and only the passing pixels' 64-byte records
 (in raster order) travel to the host, where the reference's inherently sequential locality-aware
 merge + polygon NMS runs on them (`rroi_nms_merge_host`, same arithmetic as nms.h).
@@ -15,7 +15,8 @@ import torch
 
 from ._ext import rroi_align as _ext
 
-CANDIDATE = np.dtype([("quad", "<i4", (8,)), ("score", "<f4"), ("probs", "<f4", (4,)),
+# rdist = the pixel's raw RBOX distances r[0..3]; the host merge forms the corner confidences from them
+CANDIDATE = np.dtype([("quad", "<i4", (8,)), ("score", "<f4"), ("rdist", "<f4", (4,)),
                       ("x", "<i4"), ("y", "<i4"), ("pad", "<i4")])
 assert CANDIDATE.itemsize == 64
 

@@ -178,12 +178,16 @@ int rroi_align_gt_quads_to_rois_hip(const float* quads, const float* batch_index
  *
  *    rroi_rbox_decode_hip    device: every pixel of the score map `segm` (h, w) above
  *        `segm_thresh` -> one 64-byte candidate record, in raster order: int32 quad[8] in
- *        1/10000 px, float score, float probs[4], int32 x, y, pad (adaptor.cpp:76-117).
+ *        1/10000 px, float score, float rdist[4] (the pixel's four raw RBOX distances r[0..3]; the corner
+ *        confidences expf(-r / 9) of adaptor.cpp:97-100 are formed by rroi_nms_merge_host with the C
+ *        library's expf, as the reference does), int32 x, y, pad (adaptor.cpp:76-117).
  *        rbox (4, h, w) and angle (2, h, w) are CHANNELS-FIRST, as the network emits them
  *        (the reference transposes on the host first).  *count receives the number of passing
- *        pixels even when it exceeds `capacity` (records beyond it are dropped).  One workgroup per
- *        1024 pixels; a map of more than 262144 pixels needs `capacity` >= h * w + ceil(h * w / 1024
- *        / 16) records (the library keeps its per-slab counts behind the h * w records it can fill).
+ *        pixels even when it exceeds `capacity` (records beyond it are dropped), for any `capacity` >= 0.
+ *        One workgroup per 1024 pixels.  On a map of more than 262144 pixels a buffer of `capacity` >=
+ *        h * w + ceil(h * w / 1024 / 16) records lets the library keep per-slab counts behind the h * w
+ *        records it can fill (two short launches); a smaller buffer is served by the one-launch form, in
+ *        which every workgroup counts the pixels before its slab itself (slower on such maps, same result).
  *    rroi_nms_merge_host     host (no GPU work): locality-aware merge with `iou_threshold`, then
  *        polygon NMS with `iou_threshold2` (the reference passes 0.4 and 0.2) over `num_candidates`
  *        records in host memory -> boxes (n, 9) fp32 [x0,y0,..,x3,y3 in px, score]; returns the

@@ -77,6 +77,7 @@ def decode(segm, geo, angle, segm_thresh):
             ]
             polys.append(dict(poly=quad, score=F(segm[y, x]),
                               probs=[F(p_left * p_bt), F(p_left * p_top), F(p_right * p_top), F(p_right * p_bt)],
+                              rdist=[F(r[0]), F(r[1]), F(r[2]), F(r[3])],   # what the product's record carries
                               x=x, y=y))
     return polys
 

@@ -45,7 +45,7 @@ def main():
         rec = np.zeros(len(polys), CANDIDATE)
         for i, p in enumerate(polys):
             rec[i]["quad"] = np.asarray(p["poly"], np.int64).reshape(8)
-            rec[i]["score"], rec[i]["probs"], rec[i]["x"], rec[i]["y"] = p["score"], p["probs"], p["x"], p["y"]
+            rec[i]["score"], rec[i]["rdist"], rec[i]["x"], rec[i]["y"] = p["score"], p["rdist"], p["x"], p["y"]
         got = merge(rec, w, h, iou1, iou2)
         tot["maps"] += 1
         tot["candidates"] += len(polys)
