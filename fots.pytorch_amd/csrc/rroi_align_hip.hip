@@ -26,7 +26,6 @@
 // recipe, descriptor helpers), rroi_forward_kernels.h, rroi_backward_kernels.h,
 // rroi_callers_kernels.h, rroi_nms_kernels.h (+ rroi_nms_host.h, host C++).
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <math.h>
@@ -118,8 +117,6 @@ int g_shift_pre = 1;        // SHIFT: runs that start inside a block begin with 
 int g_shift_parts = 0;      // exploration: > 0 forces the runs per (roi, chunk) block
 int g_shift_wgs_per_cu = 0;   // exploration: > 0 overrides the SHIFT kernels' workgroups per CU
 int g_fwd_shift = 1;  // 1: crops with PH * PW % 16 != 0 take the split kernel's SHIFT form
-int g_fwd_dyn_tail = 1;  // the strided items a slot would get beyond items / slots are claimed (round 4)
-int g_fwd_anyorder = 0;  // EXPERIMENT (round 4): the gather's AQL packet without the barrier bit
 int g_fwd_split = 1;  // 1: loads and stores in different waves (rroi_fwd_split_kernel) for NCHW crops
 
 int tiled_grid(long items, int nchunks, int per_cu = 0)
@@ -175,7 +172,6 @@ PatchMap make_patch_map(int pooled_height, int pooled_width)
 
 struct Workspace {
     Affine* aff;
-    unsigned* tail;   // 8 x kTailShards counters of the gather's dynamic tail (cleared by every prologue)
     float* cm;
     size_t cm_bytes;
     size_t bytes;
@@ -187,9 +183,8 @@ Workspace carve(void* ws, int batch_size, int channels, int height, int width, i
                 int layout)
 {
     Workspace w;
-    const size_t aff_bytes = align_up((size_t)(num_rois > 0 ? num_rois : 1) * sizeof(Affine), 256) + 512;
+    const size_t aff_bytes = align_up((size_t)(num_rois > 0 ? num_rois : 1) * sizeof(Affine), 256);
     const size_t nchunks = (channels + kChunk - 1) / kChunk;
-    w.tail = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + aff_bytes - 512);
     w.cm_bytes = layout == RROI_LAYOUT_NHWC
                      ? 0
                      : align_up((size_t)batch_size * nchunks * ((size_t)height * row_pitch(width) + 1) * kLineBytes, 256);
@@ -536,7 +531,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
                        make_fastdiv((unsigned)width), nchunks, ptiles, relayout_blocks,               \
                        relayout_tiles, batch_size, rois, num_rois, pooled_height,                     \
                        spatial_scale, ws.aff, aff_blocks, launcher_rest ? top_data : (float*)nullptr, \
-                       pooled_width, ws.tail)
+                       pooled_width)
         if (g_prologue_aux == 16) RROI_LAUNCH_PRO(16);
         else RROI_LAUNCH_PRO(0);
 #undef RROI_LAUNCH_PRO
@@ -596,14 +591,10 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         // to four interleaved rounds): as fast as <2, 1, 5, 2> with 10 per CU on the default draw (step 53.5-53.75
         // against 53.45-53.85 us, gather alone 44.5-44.9 against 45.5-46.1) and faster where the gatherer waves are the
         // critical path -- every bin active (w = 8 h): step 55.4-55.9 against 57.0-57.3 us
-        // dynamic tail: needs the counters the prologue clears (not with channels-last features consumed in place: no
-        // prologue relayout, but the affine blocks run there too) and at most 8 chunk counters ... at least 4 items per slot
-        const bool dyn_tail = g_fwd_dyn_tail && (stages & RROI_STAGE_PROLOGUE) && !zero_copy && nchunks <= 8 && (long)num_rois * ntiles / std::max(1, sgrid / nchunks) >= 4;
 #define RROI_LAUNCH_SPLIT(VEC)                                                                           \
-    hipExtLaunchKernelGGL((rroi_fwd_split_kernel<VEC, 2, 0, 1, 6, 3>), dim3(sgrid), dim3(2 * kWave), 0, stream, nullptr, nullptr, \
-                       g_fwd_anyorder ? hipExtAnyOrderLaunch : 0, map, \
+    hipLaunchKernelGGL((rroi_fwd_split_kernel<VEC, 2, 0, 1, 6, 3>), dim3(sgrid), dim3(2 * kWave), 0, stream, map, \
                        ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size, \
-                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg | (launcher_rest ? 32 : 0) | (dyn_tail ? 128 : 0), ws.tail)
+                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg | (launcher_rest ? 32 : 0))
         // channels-last crops: the split kernel behind the prologue (55.2 against 56.4-58.6 us at cfg2); with
         // channels-last features consumed in place the one-wave kernel is as fast or faster (51.6 against 52.3)
         if (out_nhwc && !zero_copy && g_fwd_split && g_store_aux == 2)
@@ -714,18 +705,6 @@ int rroi_align_debug_set_fwd_shift(int v, int wgs_per_cu, int parts)
 int rroi_align_debug_set_wg_trace(unsigned* device_buffer)
 {
     return status_of(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace), &device_buffer, sizeof(device_buffer)));
-}
-int rroi_align_debug_set_fwd_dyn_tail(int v)
-{
-    const int old = g_fwd_dyn_tail;
-    g_fwd_dyn_tail = v;
-    return old;
-}
-int rroi_align_debug_set_fwd_anyorder(int v)
-{
-    const int old = g_fwd_anyorder;
-    g_fwd_anyorder = v;
-    return old;
 }
 int rroi_align_debug_set_bwd_buckets(int v)
 {

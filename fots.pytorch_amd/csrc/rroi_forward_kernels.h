@@ -9,12 +9,11 @@
 //   blocks [0, relayout_blocks)      NCHW -> chunk-major: a [32 ch] x [128 px] tile goes
 //                                    through LDS; reads are 512 B runs of a channel row,
 //                                    writes are one contiguous 16 KiB run of the slice;
-//   then the rest                    per-ROI affine table (R x 32 B) (+ the gather's tail counters cleared).
+//   then the rest                    per-ROI affine table (R x 32 B).
 // (Every slice of the copy still ENDS in one spare pixel -- rounds 1-3 kept a zero pixel there for invalid taps;
 // they have pointed at out-of-range descriptor offsets since round 1 and nothing reads it, so nothing writes it.)
 // ------------------------------------------------------------------------------------
 constexpr int kRelayoutPx = 128;
-constexpr unsigned kTailShards = 16;   // claim counters per channel chunk (dynamic tail of the split gather)
 
 // The relayout proper, shared by the forward prologue (feature map) and the backward (top_diff,
 // R "images" of PH x PW "pixels").  MASK: image b is ROI b and pixels (ph, pw) with
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
     FastDiv div_w, int nchunks, int ptiles, int relayout_blocks, int relayout_tiles,
     int batch_size, const float* __restrict__ rois, int num_rois, int pooled_height,
     float spatial_scale, Affine* __restrict__ aff, int aff_blocks = 0, float* __restrict__ rest_out = nullptr,
-    int pooled_width = 0, unsigned* __restrict__ tail_cnt = nullptr)
+    int pooled_width = 0)
 {
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
     const int tid = threadIdx.x;
@@ -222,7 +221,6 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
     if ((int)blockIdx.x >= relayout_blocks) {
         const int n = ((int)blockIdx.x - relayout_blocks) * 256 + tid;
         if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
-        if (tail_cnt && n < 8 * kTailShards) tail_cnt[n] = 0u;   // the gather's dynamic-tail counters (rroi_fwd_split_kernel)
         return;
     }
     relayout_run<AUX, false>(T, nchw, cm, C, HW, width, pitch, div_w, nchunks, ptiles, (int)blockIdx.x,
@@ -663,8 +661,7 @@ template <bool VEC_STORE, int AUX, int EARLY = 2, int MINOR = 1, int OCC = 5, in
 __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
-    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg,
-    unsigned* __restrict__ tail_cnt = nullptr)
+    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg)
 {
     // A tile's bins are processed in CLASS-SORTED groups of 8, because the texture addresser
     // charges 16 cycles for every dwordx4 wave instruction whatever the number of lanes that
@@ -699,7 +696,6 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     __shared__ __attribute__((aligned(16))) uint4 Gbuf[2 * kRecs];
     __shared__ unsigned char HPbuf[2 * kRecs];
     __shared__ uint4 shead[2];  // per record set: LO groups, HI groups, mask of the bins that are in a group
-    __shared__ unsigned sclaim; // dynamic tail: the item the gatherer claimed for this workgroup (kEnd: none)
 
     const unsigned lane = threadIdx.x & 63u;
     // wave 0 gathers (loads only), wave 1 streams the finished tiles out (stores only)
@@ -1098,26 +1094,8 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             return rn * (unsigned)ntiles + part * len - (cur_pre ? 1u : 0u);
         }
     };
-    // Dynamic tail (dbg & 128, strided items only; round 4).  Every workgroup takes its J = items / nslots strided
-    // items as before; the items - J * nslots left over (fewer than nslots) are not dealt to the first slots but
-    // CLAIMED, first come first served: per-workgroup time stamps showed that the workgroups' progress differs by
-    // up to 9 us from the launch's first microseconds on (the first tiles of 3072 workgroups are gathered at once)
-    // and stays that way, so the workgroups that are ahead should be the ones that take an eleventh item.
-    // Same-address atomics serialise (tens of ns each): the pool of a chunk is dealt to kTailShards counters, slot s
-    // claims from shard s % kTailShards, whose items are static_end + shard + r * kTailShards.  The gatherer issues
-    // the claim at the end of static item J - 3 -- two items before the answer is needed, no load in flight at that
-    // point -- reads it at the end of item J - 2 and hands it to the storer through LDS before barrier 1 of item
-    // J - 1.  tail_cnt[k * kTailShards + shard] is cleared by the prologue launch of the same call.
-    const unsigned J = items / nslots;
-    const bool dyn = !SHIFT && (dbg & 128) && J >= 4u;
-    const unsigned static_end = dyn ? J * nslots : items;
-    unsigned claimed = kEnd;   // (the gatherer's copy; the storer reads sclaim)
     auto next = [&](unsigned c) -> unsigned {
-        if (!SHIFT) {
-            if (c + nslots < static_end) return c + nslots;
-            // behind the last static item: the claimed one, if any; behind that, nothing
-            return (dyn && c < static_end) ? (storer ? sclaim : claimed) : kEnd;
-        }
+        if (!SHIFT) return c + nslots < items ? c + nslots : kEnd;
         cur_pre = false;
         if (c + 1u < run_end) return c + 1u;
         run += nslots;
@@ -1212,8 +1190,6 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // not urgent: with the gatherer ahead in the issue arbitration the call is 0.7 us shorter (any level > 0)
     __builtin_amdgcn_s_setprio(2);
     unsigned p = 0;
-    unsigned claim_raw = 0;
-    const unsigned claim_at = slot + (J - 3u) * nslots, read_at = slot + (J - 2u) * nslots;
     for (;; cur = next(cur), p ^= 1u) {
         wg_lds_barrier();  // 1: the storer has put this item's records into set p (and our previous tile is complete)
         if (cur == kEnd) {
@@ -1321,17 +1297,6 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                     asm volatile("; hi: last group");
                     break;
                 }
-            }
-        }
-        if (dyn) {
-            // (no tap load is in flight here: the claim's round trip runs under item J - 2)
-            const unsigned shard = slot % kTailShards;
-            if (cur == claim_at && lane == 0) claim_raw = atomicAdd(tail_cnt + k * kTailShards + shard, 1u);
-            if (cur == read_at) {
-                const unsigned r = (unsigned)__builtin_amdgcn_readfirstlane((int)claim_raw);
-                const unsigned item = static_end + shard + r * kTailShards;
-                claimed = (r < nslots && item < items) ? item : kEnd;
-                if (lane == 0) sclaim = claimed;   // read by the storer behind barrier 1 of item J - 1
             }
         }
     }

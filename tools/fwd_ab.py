@@ -3,7 +3,9 @@
 (tools/build_explore.sh): the gather's left-over items claimed dynamically (dyn_tail) against dealt to the first slots;
 the gather's AQL packet with / without the barrier bit (hipExtAnyOrderLaunch); prologue stores plain / write-through.
 HIP events around back-to-back calls, interleaved rounds; every variant's crops compared with the first call's.
-    python tools/fwd_ab.py [rounds] [all_active]"""
+    python tools/fwd_ab.py [rounds] [all_active]
+Needs tools/experiments/r04_forward_tail_experiments.patch applied (`git apply` it, `sh tools/build_explore.sh`): the
+dynamic tail and the any-order launch were measured and NOT shipped (profiles/r04_forward_floor.md)."""
 import ctypes
 import json
 import os
