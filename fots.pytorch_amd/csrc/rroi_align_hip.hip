@@ -1156,6 +1156,20 @@ int rroi_ctc_greedy_decode_hip(const float* logits, int num_seqs, int num_classe
     return launch_status();
 }
 
+int rroi_align_set_trig_recipe_hip(int recipe)
+{
+    if (recipe != RROI_TRIG_DOUBLE && recipe != RROI_TRIG_FP32) return 0;
+    // (synchronous, like any write to a __device__ variable: it is ordered behind the launches already enqueued)
+    return status_of(hipMemcpyToSymbol(HIP_SYMBOL(g_trig_recipe), &recipe, sizeof(recipe)));
+}
+
+int rroi_align_get_trig_recipe_hip(void)
+{
+    int recipe = -1;
+    const hipError_t e = hipMemcpyFromSymbol(&recipe, HIP_SYMBOL(g_trig_recipe), sizeof(recipe));
+    return e == hipSuccess ? recipe : -(int)e;
+}
+
 int rroi_align_sincos_probe_hip(const float* angle_deg, int n, float* out, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);

@@ -58,10 +58,24 @@ __device__ __forceinline__ int f2i_sat(float x)
     return r;
 }
 
+// The one library-dependent step of the arithmetic recipe (kernel.cu:73-74: `cos(angle)`, `sin(angle)` of a float).
+//   0 (default)  (float)cos((double)angle): the correctly rounded cosine up to a double rounding -- what
+//                oracle/rroi_align_oracle.c evaluates with the host's libm, identical on the device (2.7 M angles,
+//                test_sincos_recipe_matches_host_libm);
+//   1 (opt-in)   cosf(angle) / sinf(angle) in fp32, i.e. this toolchain's device library (ocml) -- what the
+//                reference's OWN sources become when they are built for this GPU.  Neither float cosine is
+//                correctly rounded, so recipe 0 and a float-cosine build differ in the last place for some angles,
+//                and where that meets a rounding tie a bin's sample point moves (15-17 bins per million,
+//                profiles/r03_fuzz_ref*.json); with recipe 1 the product and the reference's build for gfx950
+//                agree in EVERY bin (tests/test_gpu_vs_reference.py::test_ocml_trig_recipe_moves_no_bin).
+// Per device (a __device__ variable); set with rroi_align_set_trig_recipe_hip().
+__device__ int g_trig_recipe = 0;
+
 // kernel.cu:58-84.  Every * and + below is one separately rounded fp32
 // operation, in source order; the degree->radian conversion is the
 // reference's double expression (:65); cos/sin are evaluated in double and
-// rounded once to fp32 (recipe shared with oracle/rroi_align_oracle.c).
+// rounded once to fp32 (recipe shared with oracle/rroi_align_oracle.c) unless
+// the fp32 recipe has been asked for (g_trig_recipe above).
 __device__ __forceinline__ Affine make_affine(const float* __restrict__ roi, int pooled_height,
                                               float spatial_scale)
 {
@@ -74,8 +88,14 @@ __device__ __forceinline__ Affine make_affine(const float* __restrict__ roi, int
     const float dy = (float)(-pooled_height / 2.0);
     const float Sx = (w * spatial_scale) / rpw;
     const float Sy = (h * spatial_scale) / (float)pooled_height;
-    const float Alpha = (float)cos((double)angle);
-    const float Beta = (float)sin((double)angle);
+    float Alpha, Beta;
+    if (g_trig_recipe == 1) {
+        Alpha = cosf(angle);
+        Beta = sinf(angle);
+    } else {
+        Alpha = (float)cos((double)angle);
+        Beta = (float)sin((double)angle);
+    }
     const float Dx = cx * spatial_scale;
     const float Dy = cy * spatial_scale;
     A.m00 = Alpha * Sx;

@@ -71,6 +71,10 @@ _lib.rroi_ctc_greedy_decode_hip.restype = _i
 _lib.rroi_ctc_greedy_decode_hip.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.rroi_align_sincos_probe_hip.restype = _i
 _lib.rroi_align_sincos_probe_hip.argtypes = [_vp, _i, _vp, _vp]
+_lib.rroi_align_set_trig_recipe_hip.restype = _i
+_lib.rroi_align_set_trig_recipe_hip.argtypes = [_i]
+_lib.rroi_align_get_trig_recipe_hip.restype = _i
+_lib.rroi_align_get_trig_recipe_hip.argtypes = []
 _lib.RROIAlignForwardLaucher.restype = _i
 _lib.RROIAlignForwardLaucher.argtypes = [_vp, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.RROIAlignBackwardLaucher.restype = _i
@@ -85,12 +89,28 @@ EXPORTS = (
     "rroi_align_sincos_probe_hip", "rroi_align_quads_to_rois_hip", "rroi_align_hip_version",
     "rroi_ctc_greedy_decode_hip", "rroi_align_backward_layout_hip", "rroi_align_forward_layout_hip",
     "rroi_align_gt_quads_to_rois_hip", "rroi_rbox_decode_hip", "rroi_nms_merge_host",
-    "rroi_align_release_launcher_scratch",
+    "rroi_align_release_launcher_scratch", "rroi_align_set_trig_recipe_hip", "rroi_align_get_trig_recipe_hip",
 )
 
 
 def version() -> str:
     return _lib.rroi_align_hip_version().decode()
+
+
+TRIG_DOUBLE, TRIG_FP32 = 0, 1
+
+
+def set_trig_recipe(recipe: int, device=None) -> int:
+    """cos / sin of the ROI angle (rroi_align_kernel.cu:73-74) on `device` (default: the current one):
+    TRIG_DOUBLE (default; the oracle's recipe, (float)cos((double)angle)) or TRIG_FP32 (the device library's
+    cosf / sinf -- what the reference's own sources evaluate when built for this GPU; bit-exact against that
+    build in every bin).  Returns the previous recipe.  Synchronises with the device."""
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        old = _lib.rroi_align_get_trig_recipe_hip()
+        if old < 0:
+            raise RuntimeError(f"rroi_align_get_trig_recipe_hip: HIP error {-old}")
+        _check(_lib.rroi_align_set_trig_recipe_hip(int(recipe)), "rroi_align_set_trig_recipe_hip")
+    return old
 
 
 def _check(status: int, what: str) -> None:

@@ -223,6 +223,19 @@ int rroi_align_bin_centres_hip(float spatial_scale, int num_rois, int height, in
  * library-dependent step of the arithmetic recipe). out = (n, 2). */
 int rroi_align_sincos_probe_hip(const float* angle_deg, int n, float* out, void* stream);
 
+/* The one library-dependent step of the arithmetic (rroi_align_kernel.cu:73-74, `cos(angle)` / `sin(angle)` of a
+ * float).  RROI_TRIG_DOUBLE (default): (float)cos((double)angle), the recipe of the oracle -- bit-exact against it
+ * and against the reference's sources evaluated with a correctly rounded cosine.  RROI_TRIG_FP32: cosf / sinf of
+ * the device library, what the reference's own sources call when they are built for this GPU -- bit-exact, every
+ * bin, against that build (oracle/_ref/librroi_ref_hip_nofma.so).  The two differ in 15-17 bins per million, at
+ * rounding ties.  The setting is PER DEVICE (the current one), applies to every entry point that derives an affine
+ * from ROIs (forward, backward, bin centres, the reference-ABI launchers), and the setter synchronises with the
+ * device.  set: 1 ok / 0 invalid recipe / -hipError; get: the recipe, or -hipError. */
+#define RROI_TRIG_DOUBLE 0
+#define RROI_TRIG_FP32 1
+int rroi_align_set_trig_recipe_hip(int recipe);
+int rroi_align_get_trig_recipe_hip(void);
+
 /* Identification: "rroi_align_hip <version> gfx950". */
 const char* rroi_align_hip_version(void);
 

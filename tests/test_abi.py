@@ -141,8 +141,8 @@ def test_python_constants_are_the_headers():
     import re
     from rroi_align._ext import rroi_align as ext
     text = open(os.path.join(ROOT, "include", "rroi_align_hip.h")).read()
-    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+RROI_((?:PATH|LAYOUT)_\w+)\s+(\d+)", text)}
-    assert len(defs) >= 9
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+RROI_((?:PATH|LAYOUT|TRIG)_\w+)\s+(\d+)", text)}
+    assert len(defs) >= 11 and "TRIG_FP32" in defs
     for name, value in defs.items():
         assert getattr(ext, name) == value, name
     assert set(ext.BACKWARD_PATHS) == {v for k, v in defs.items() if k.startswith("PATH_")}

@@ -150,3 +150,58 @@ def test_cos_sin_recipe_drift_budget_against_the_reference_build(ref):
     assert wrong_elsewhere == 0, "outputs differ although the sample points agree"
     assert moved <= 50e-6 * bins, (moved, bins)      # measured: 16.8 per million on this mix
     assert shift <= 1.0
+
+
+def test_ocml_trig_recipe_moves_no_bin(ref):
+    """the opt-in fp32 recipe (ext.set_trig_recipe(ext.TRIG_FP32): cosf / sinf of the device
+    library, as the reference's sources call them, kernel.cu:73-74) against the reference's own kernels built for
+    this GPU: >= 33 M bins over all angles, a quarter of the ROIs on rounding ties (the mix on which the default
+    recipe moves 16.8 bins per million) -- NO bin's sample point moves, no output element differs, on either
+    forward path; con_idx through the reference-ABI entry point identical too.  The default recipe (and with it the
+    oracle parity of every other test) is restored afterwards."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_ref", os.path.join(os.path.dirname(REFDIR), "..", "tools", "fuzz_ref.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from rroi_align._ext import rroi_align as ext
+    rng = np.random.default_rng(11)          # the seed of profiles/r03_fuzz_ref.json
+    ph, pw, s, H, W = 8, 64, 0.25, 160, 160
+    F = torch.from_numpy(rng.standard_normal((1, 1, H, W), dtype=np.float32)).cuda()
+    old = ext.set_trig_recipe(ext.TRIG_FP32)
+    try:
+        assert old == ext.TRIG_DOUBLE
+        bins = moved = differ = 0
+        for rnd in range(16):
+            r = fz.random_rois(rng, 4096)
+            R = torch.from_numpy(r).cuda()
+            want, ix, iy = ref_forward(ref, F, R, ph, pw, s)
+            geom = ext.bin_centres(R, ph, pw, s, H, W)
+            moved += int(((geom[..., 0] != ix[:, 0]) | (geom[..., 1] != iy[:, 0])).sum())
+            for path in (ext.PATH_TILED, ext.PATH_DIRECT):
+                got = ext.forward(F, R, ph, pw, s, path=path)
+                differ += int((~((got == want) | (got.isnan() & want.isnan()))).sum())
+            bins += geom[..., 0].numel()
+            if rnd == 0:   # the reference-ABI entry point of this library, con_idx included
+                out2, ix2, iy2 = (torch.empty_like(want) for _ in range(3))
+                assert ext.rroi_align_forward_cuda(ph, pw, s, F, R, out2, ix2, iy2) == 1
+                assert torch.equal(ix2, ix) and torch.equal(iy2, iy)
+                assert bool(((out2 == want) | (out2.isnan() & want.isnan())).all())
+        assert bins >= 33_000_000
+        assert moved == 0 and differ == 0, (moved, differ, bins)
+        # training-like pooled shape (11 x 83: the SHIFT kernels), several images, through the backward as well
+        f, r = Wk.bench_inputs(R=400, C=64, H=120, W=160, img=640, seed=8, batch=2)
+        F2, R2 = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
+        want, ix, iy = ref_forward(ref, F2, R2, 11, 83, 0.25)
+        assert torch.equal(ext.forward(F2, R2, 11, 83, 0.25), want)
+        gout = torch.randn_like(want)
+        gwant = torch.zeros_like(F2)
+        ref.RROIAlignBackwardLaucher(gout.data_ptr(), 0.25, 2, 400, 120, 160, 64, 11, 83, R2.data_ptr(), gwant.data_ptr(),
+                                     ix.data_ptr(), iy.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        got = ext.backward(gout, R2, f.shape, 0.25)
+        assert float((got - gwant).abs().max()) <= 1e-4 * float(gwant.abs().max())
+    finally:
+        ext.set_trig_recipe(old)
+    assert ext.set_trig_recipe(ext.TRIG_DOUBLE) == ext.TRIG_DOUBLE
+    with pytest.raises(ValueError):
+        ext.set_trig_recipe(7)
