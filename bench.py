@@ -92,6 +92,23 @@ def cpu_baseline(feats, rois):
     O.forward_literal_c(feats, rois[:4], c["PH"], c["PW"], c["scale"])
     t_lit = (time.perf_counter() - t0) / 4.0
     touched = O.touched_pixels(rois, 1, c["H"], c["W"], c["PH"], c["PW"], c["scale"])
+    # configs[2], BASELINE.md section 2 last row: the backward of the same shapes (oracle, hoisted, a thread owns
+    # a set of channels; double accumulation), single thread and all cores, full workload
+    gout = np.random.default_rng(1).standard_normal((len(rois), c["C"], c["PH"], c["PW"]), dtype=np.float32)
+    t0 = time.perf_counter()
+    O.backward_c(gout, rois, feats.shape, c["scale"], threads=1)
+    tb1 = time.perf_counter() - t0
+    tbn = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.backward_c(gout, rois, feats.shape, c["scale"], threads=cores)
+        tbn = min(tbn, time.perf_counter() - t0)
+    del gout
+    backward = {"ms_per_call": round(tbn * 1e3, 2), "cores": cores, "ms_per_call_single_thread": round(tb1 * 1e3, 2),
+                "unit": "ms", "kind": "port",
+                "sample": "full workload (grad_out 512 x 256 x 8 x 64 -> grad_in 1 x 256 x 160 x 160), oracle "
+                          "rroi_oracle_backward_mt (kernel.cu:193-278 semantics, geometry once per bin, channels dealt to "
+                          "the threads, double accumulation), best of 3 on all cores / one run on one thread"}
     return {
         "value": round(len(rois) / best, 1), "unit": "ROIs/s", "cores": cores, "kind": "port",
         "sample": "full workload (512 ROIs x 256 ch x 8x64), oracle/rroi_align_oracle.c hoisted "
@@ -99,7 +116,62 @@ def cpu_baseline(feats, rois):
                   "%.1f ROIs/s; literal per-element form of the reference kernel, single thread "
                   "(4-ROI sample): %.1f ROIs/s" % (len(rois) / t1, 1.0 / t_lit),
         "ms_per_step": round(best * 1e3, 2),
+        "backward": backward,
     }, touched
+
+
+def train_regime(ext, dev, event_loop):
+    """the reference's OWN training call (src/ocr_process.py:259-267: pooled_height 11,
+    pooled_width = ceil(11 * max w / h) -- any integer), on its 64-channel 1/4 map: forward and backward per shape
+    with algorithmic bytes and the fraction of the 8 TB/s peak.  Not part of `value`."""
+    B, C, H, W, scale = 2, 64, 120, 160, 0.25
+    stream = torch.cuda.current_stream().cuda_stream
+    rows = {}
+    for PW in (83, 100, 96):          # 11 x 96 is the aligned shape the SHIFT kernels are held against
+        for R in (32, 512):
+            rng = np.random.default_rng(1000 + R + PW)
+            feats = torch.from_numpy(rng.standard_normal((B, C, H, W), dtype=np.float32)).to(dev)
+            h = rng.uniform(16, 64, R)
+            rois = torch.from_numpy(np.stack([rng.integers(0, B, R), rng.uniform(0, 4 * W, R), rng.uniform(0, 4 * H, R), h,
+                                              h * rng.uniform(2, PW / 11.0, R), rng.uniform(-45, 45, R)], 1).astype(np.float32)).to(dev)
+            out = torch.empty((R, C, 11, PW), dtype=torch.float32, device=dev)
+            gout = torch.randn_like(out)
+            gin = torch.empty_like(feats)
+            nf = ext._lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, ext.LAYOUT_NCHW)
+            nb = ext._lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, 11, PW)
+            ws = torch.empty(max(nf, nb, 1), dtype=torch.uint8, device=dev)
+
+            def fwd():
+                st = ext._lib.rroi_align_forward_hip(feats.data_ptr(), ext.LAYOUT_NCHW, scale, B, R, H, W, C, 11, PW,
+                                                     rois.data_ptr(), out.data_ptr(), ws.data_ptr(), nf, ext.PATH_AUTO, stream)
+                if st != 1:
+                    raise RuntimeError(f"train_regime forward -> {st}")
+
+            def bwd():
+                st = ext._lib.rroi_align_backward_hip(gout.data_ptr(), scale, B, R, H, W, C, 11, PW, rois.data_ptr(),
+                                                      gin.data_ptr(), ws.data_ptr(), nb, ext.PATH_AUTO, stream)
+                if st != 1:
+                    raise RuntimeError(f"train_regime backward -> {st}")
+            f_ms, b_ms = event_loop(fwd, 50, 200), event_loop(bwd, 20, 100)
+            # algorithmic bytes: crops + rois + the map once (an upper bound of the touched pixels; at R = 32 most of the
+            # map is not touched, so the forward's fraction is an overestimate there -- the call still relays it out)
+            crops, fmap = R * C * 11 * PW * 4, B * C * H * W * 4
+            fb, bb = crops + R * 24 + fmap, crops + R * 24 + fmap
+            rows["11x%d_R%d" % (PW, R)] = {
+                "forward_us": round(f_ms * 1e3, 2), "backward_us": round(b_ms * 1e3, 2),
+                "forward_algorithmic_bytes": fb, "backward_algorithmic_bytes": bb,
+                "forward_frac_of_peak": round(fb / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "backward_frac_of_peak": round(bb / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del feats, rois, out, gout, gin, ws
+    for PW in (83, 100):
+        for R in (32, 512):
+            rows["11x%d_R%d" % (PW, R)]["forward_vs_aligned_11x96"] = round(
+                rows["11x%d_R%d" % (PW, R)]["forward_us"] / rows["11x96_R%d" % R]["forward_us"] / (PW / 96.0), 3)
+    rows["what"] = ("the reference's training call (src/ocr_process.py:259-267): %d images of %d x %d x %d, pooled 11 x PW, "
+                    "R ROIs over the images, PATH_AUTO, 200 / 100 back-to-back calls between HIP events; bytes = crops + "
+                    "rois + the whole map once; forward_vs_aligned_11x96 = time per output byte against the 11 x 96 shape "
+                    "(rows of whole 64-byte sectors) at the same R" % (B, C, H, W))
+    return rows
 
 
 def _free_port():
@@ -379,6 +451,13 @@ def run(args):
         bwd_cl_ms = event_loop(bwd_cl, 10, 50)
         del gout, gout_cl, ws_b, gin
 
+    train = None
+    if world == 1 and os.environ.get("RROI_BENCH_TRAIN", "1") == "1":
+        try:
+            train = train_regime(ext, dev, event_loop)
+        except Exception as e:
+            train = {"error": repr(e)[:300]}
+
     # spread of the call, measured LAST among the kernel timings (200 interleaved event records leave the
     # runtime ~3.5 us per call slower for what follows in the process -- measured, cause not pursued)
     if world == 1:
@@ -397,7 +476,16 @@ def run(args):
                       "p90": round(float(d[(9 * n_s) // 10]), 5),
                       "how": "one HIP event after every call, 200 calls, differences of consecutive events"}
 
-    # calibration of the bound on this box: a plain device fill of the same 256 MiB output buffer
+    # calibration of the bound on this box: what plain writes of the same 256 MiB buffer reach.  Zeros are a special
+    # case on this chip (8 TB/s; the data-dependent part of the power budget is idle); the gather writes feature
+    # data, so its ceiling is a write of NON-ZERO data: a constant (fill_(1.0)) and values that differ from store to store
+    # (the library's write probe: one 16-byte plain store per thread, torch's elementwise launch shape).  Run last: a stretch of zero fills slows what follows.
+    flat = out.view(-1)
+    fill_one_ms = event_loop(lambda: out.fill_(1.0), 10, 40)
+    def write_probe():
+        if ext._lib.rroi_align_write_probe_hip(out.data_ptr(), flat.numel(), stream) != 1:
+            raise RuntimeError("rroi_align_write_probe_hip")
+    probe_ms = event_loop(write_probe, 10, 40)
     fill_ms = event_loop(lambda: out.fill_(0.0), 10, 40)
     launch(ext.STAGE_ALL)  # leave the real result in `out`
     torch.cuda.synchronize()
@@ -406,7 +494,8 @@ def run(args):
     e2e = None
     if world == 1 and os.environ.get("RROI_BENCH_E2E", "1") == "1":
         try:
-            from fots_e2e.bench_e2e import measure as e2e_measure
+            sys.path.insert(0, ROOT)
+            from bench_e2e import measure as e2e_measure
             e2e = e2e_measure(dev)
         except Exception as e:
             e2e = {"error": repr(e)[:300]}
@@ -437,6 +526,17 @@ def run(args):
     gather_in_step_ms = max(step_events_ms - prologue_ms, 1e-6)
     achieved = b_alg / (gather_in_step_ms * 1e-3) / 1e9
     fill_gbs = out.numel() * 4 / (fill_ms * 1e-3) / 1e9
+    fill_one_gbs = out.numel() * 4 / (fill_one_ms * 1e-3) / 1e9
+    probe_gbs = out.numel() * 4 / (probe_ms * 1e-3) / 1e9
+    nonzero_gbs = max(fill_one_gbs, probe_gbs)
+
+    bwd_prof = None
+    bpath = os.path.join(ROOT, "profiles", "bwd_traffic.json")  # rocprofv3 kernel trace + PMC passes over the backward
+    if os.path.exists(bpath):
+        try:
+            bwd_prof = json.load(open(bpath))
+        except Exception:
+            bwd_prof = None
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes/launch, if collected
@@ -474,8 +574,20 @@ def run(args):
                      "prologue_ms_avg": round(prologue_ms, 5),
                      "whole_call_ms_events": round(step_events_ms, 5),
                      "whole_call_ms_spread": step_stats,
-                     "calibrated": {"what": "torch fill_ of the 256 MiB output buffer on this GPU (40 back-to-back)",
-                                    "GB/s": round(fill_gbs, 1), "frac_of_it": round(achieved / fill_gbs, 4)}},
+                     "calibrated": {"what": "torch fill_(0.0) of the 256 MiB output buffer on this GPU (40 back-to-back): "
+                                            "ZEROS, which this chip writes faster than any other data -- kept for "
+                                            "continuity with rounds 1-3, not the gather's ceiling",
+                                    "GB/s": round(fill_gbs, 1), "frac_of_it": round(achieved / fill_gbs, 4)},
+                     "calibrated_nonzero": {
+                         "what": "plain writes of NON-ZERO data into the same 256 MiB buffer, 40 back-to-back each: "
+                                 "fill_(1.0) (a constant) and rroi_align_write_probe_hip (values that differ from store to "
+                                 "store, one 16-byte plain store per thread = torch's elementwise launch shape); the better "
+                                 "of the two is the ceiling the gather's output stream is held against "
+                                 "(profiles/r04_write_ceiling.txt: the same by store policy, tools/kbench wceil)",
+                         "fill_one_GB/s": round(fill_one_gbs, 1), "nonconstant_GB/s": round(probe_gbs, 1),
+                         "GB/s": round(nonzero_gbs, 1),
+                         "frac_of_it": round(achieved / nonzero_gbs, 4),
+                         "output_stream_frac_of_it": round(bytes_out / (gather_in_step_ms * 1e-3) / 1e9 / nonzero_gbs, 4)}},
         "cpu_baseline": cpu,
         "extra": {
             "sensitivity": sensitivity,
@@ -500,7 +612,17 @@ def run(args):
                 "algorithmic_bytes": int(R * c["C"] * c["PH"] * c["PW"] * 4 + c["C"] * c["H"] * c["W"] * 4 + R * 24),
                 "frac_of_peak_whole_call": round((R * c["C"] * c["PH"] * c["PW"] * 4 + c["C"] * c["H"] * c["W"] * 4 + R * 24)
                                                  / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "ms_per_call_channels_last": round(bwd_cl_ms, 5)},  # top_diff and the feature gradient both channels_last
+                "ms_per_call_channels_last": round(bwd_cl_ms, 5),  # top_diff and the feature gradient both channels_last
+                # per-kernel durations and fabric traffic of the same call: rocprofv3 kernel trace + separate --pmc passes
+                # (tools/profile_bwd.sh -> profiles/bwd_traffic.json), collected once per round, not in this run
+                "roofline": None if bwd_prof is None else dict(
+                    bwd_prof, bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s",
+                    achieved=round((R * c["C"] * c["PH"] * c["PW"] * 4 + c["C"] * c["H"] * c["W"] * 4 + R * 24)
+                                   / (bwd_ms * 1e-3) / 1e9, 1),
+                    wasted_traffic_ratio=None if not bwd_prof.get("traffic_bytes_per_call") else round(
+                        bwd_prof["traffic_bytes_per_call"]
+                        / (R * c["C"] * c["PH"] * c["PW"] * 4 + c["C"] * c["H"] * c["W"] * 4 + R * 24), 3))},
+            "train_regime": train,
             "e2e": e2e,
         },
     }

@@ -1,4 +1,6 @@
-"""BASELINE configs[4]: images/s of the end-to-end inference pipeline (`test.py:75-116`) on the
+"""bench_e2e.py -- benchmark code (imported by bench.py for `extra.e2e`), not part of the product package.
+
+BASELINE configs[4]: images/s of the end-to-end inference pipeline (`test.py:75-116`) on the
 reference's own test images (`data/example_image/*.jpg`, 1280x720 -> 1280x704), random weights
 (the checkpoint is not in the reference's repository), per-box vs batched recognition.
 
@@ -10,16 +12,24 @@ carries no text regions, so the detector's post-processing is measured on its ow
 """
 import glob
 import os
+import sys
 import time
 
 import numpy as np
 import torch
 
-from .alphabet import ALPHABET
-from .hostcpus import cap_torch_threads
-from .model import FOTSNet
-from .pipeline import batched, per_box, preprocess, resize_rule, synthetic_boxes
-from .weights import deterministic_init
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "fots.pytorch_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+from fots_e2e.alphabet import ALPHABET  # noqa: E402
+from fots_e2e.hostcpus import cap_torch_threads  # noqa: E402
+from fots_e2e.model import FOTSNet  # noqa: E402
+from fots_e2e.pipeline import batched, infer_image, preprocess, resize_rule, synthetic_boxes, synthetic_detector_maps  # noqa: E402
+from fots_e2e.weights import deterministic_init  # noqa: E402
+# the baseline leg: the reference's per-word loop (checker / baseline code, kept outside the product package)
+from oracle.e2e_loop_oracle import infer_image_per_box, per_box  # noqa: E402
 
 BOXES_PER_IMAGE = 24
 
@@ -27,8 +37,7 @@ BOXES_PER_IMAGE = 24
 def load_images(limit=None):
     """Decoded uint8 BGR arrays of the reference's example images (data fixtures under
     tests/golden/ref_data), or seeded noise of the same size when they are not there."""
-    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    paths = sorted(glob.glob(os.path.join(root, "tests", "golden", "ref_data", "example_image", "*.jpg")))
+    paths = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "ref_data", "example_image", "*.jpg")))
     ims, source = [], "data/example_image/*.jpg (11 images, 1280x720)"
     try:
         from PIL import Image
@@ -93,7 +102,6 @@ def measure(device, reps=5, channels_last=False):
             same = texts if same is None else (same == texts)
     # the detector's post-processing on its own (see the module docstring): 24 words at 1280 x 704
     from rroi_align.nms import get_boxes
-    from .pipeline import infer_image, synthetic_detector_maps
     maps = [tuple(torch.from_numpy(a).to(device) for a in synthetic_detector_maps(704, 1280, BOXES_PER_IMAGE, seed=i))
             for i in range(len(ims))]
     # ---- the whole chain of test.py:75-116 per image: preprocess, net, get_boxes ON the maps (the
@@ -101,7 +109,8 @@ def measure(device, reps=5, channels_last=False):
     with torch.no_grad():
         for name in ("per_box", "batched"):
             def chain(i, im):
-                return infer_image(net, conv, im, detector=lambda _x, m=maps[i]: m, recognise=name)
+                fn = infer_image_per_box if name == "per_box" else infer_image
+                return fn(net, conv, im, detector=lambda _x, m=maps[i]: m)
             for i, im in enumerate(ims):
                 chain(i, im)                                   # warm-up
             per_image, nbox = [], 0
@@ -142,3 +151,8 @@ def measure(device, reps=5, channels_last=False):
     out["speedup"] = round(out["batched"]["images_per_s"] / out["per_box"]["images_per_s"], 2)
     out["host_threads"] = host_threads
     return out
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(measure(torch.device("cuda", 0))))

@@ -320,9 +320,16 @@ int g_bwd_buckets = 1;  // one-pass pixel lists (round 3); 0: count / scan / fil
 // Scratch of the reference-ABI launchers.  Their signatures carry no workspace, so the library keeps
 // one buffer per (device, stream), grown on demand and reused: calls on one stream are ordered, so the
 // next call may overwrite what the previous one left.  No allocator round trip per call, and a call
-// whose buffer exists enqueues kernels only -- it can be captured into a HIP graph.  (A call made WHILE
-// its stream is capturing and whose buffer would have to grow takes stream-ordered memory for that
-// call alone: the graph owns it.)  rroi_align_release_launcher_scratch() frees everything.
+// whose buffer exists enqueues kernels only -- it can be captured into a HIP graph.
+// Lifetime rules:
+//   * a buffer that has been handed out WHILE ITS STREAM WAS CAPTURING is baked into a graph: it is PINNED and
+//     never freed again -- not when a later call needs more (that call takes stream-ordered memory of its own),
+//     not by the least-recently-used eviction, not by rroi_align_release_launcher_scratch();
+//   * a call made while capturing whose buffer does not exist (or is too small) takes stream-ordered memory for
+//     that call alone: the graph owns it;
+//   * the table's lock is held from the look-up until the caller has ENQUEUED its launches (ScratchLease), so a
+//     second thread sharing the stream cannot free -- in stream order, ahead of those launches -- a buffer that
+//     the first thread is about to launch on.
 // ------------------------------------------------------------------------------------
 struct LauncherArena {
     int device;
@@ -330,6 +337,7 @@ struct LauncherArena {
     void* ptr;
     size_t bytes;
     unsigned long long last_use;
+    bool pinned;   // handed out during a stream capture: a graph replays with this address
 };
 constexpr int kMaxArenas = 16;
 std::mutex g_arena_mutex;
@@ -337,36 +345,60 @@ LauncherArena g_arenas[kMaxArenas];
 int g_num_arenas = 0;
 unsigned long long g_arena_clock = 0;
 
-// -> buffer of at least `bytes` for launches on `stream`, or nullptr with *err set.  *transient: the
-// buffer belongs to this call alone (stream capture) and must be given back with hipFreeAsync.
-void* launcher_scratch(hipStream_t stream, size_t bytes, bool* transient, hipError_t* err)
+// A buffer of at least `bytes` for launches on `stream`, held under the table's lock until give_back().
+struct ScratchLease {
+    std::unique_lock<std::mutex> lock;
+    void* ptr = nullptr;
+    bool transient = false;   // the buffer belongs to this call alone: give_back() returns it in stream order
+    hipError_t err = hipSuccess;
+    hipError_t give_back(hipStream_t stream)
+    {
+        hipError_t e = hipSuccess;
+        if (transient && ptr) e = hipFreeAsync(ptr, stream);
+        ptr = nullptr;
+        if (lock.owns_lock()) lock.unlock();
+        return e;
+    }
+};
+
+ScratchLease launcher_scratch(hipStream_t stream, size_t bytes)
 {
-    *transient = false;
-    *err = hipSuccess;
+    ScratchLease L;
     int dev = 0;
-    if ((*err = hipGetDevice(&dev)) != hipSuccess) return nullptr;
+    if ((L.err = hipGetDevice(&dev)) != hipSuccess) return L;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    L.lock = std::unique_lock<std::mutex>(g_arena_mutex);
+    auto take_transient = [&]() {
+        L.err = hipMallocAsync(&L.ptr, bytes, stream);
+        L.transient = L.err == hipSuccess;
+        if (!L.transient) L.ptr = nullptr;
+    };
     LauncherArena* a = nullptr;
     for (int i = 0; i < g_num_arenas; ++i)
         if (g_arenas[i].device == dev && g_arenas[i].stream == stream) a = &g_arenas[i];
     if (a && a->bytes >= bytes) {
         a->last_use = ++g_arena_clock;
-        return a->ptr;
+        if (capturing) a->pinned = true;
+        L.ptr = a->ptr;
+        return L;
     }
-    if (capturing) {  // do not cache memory that the graph will own
-        void* p = nullptr;
-        *err = hipMallocAsync(&p, bytes, stream);
-        *transient = *err == hipSuccess;
-        return *err == hipSuccess ? p : nullptr;
+    // no cached buffer of that size.  While capturing the graph owns what it allocates; a pinned buffer that is
+    // too small stays as it is (a graph replays with it) and this call takes memory of its own
+    if (capturing || (a && a->pinned)) {
+        take_transient();
+        return L;
     }
     if (!a) {
         if (g_num_arenas == kMaxArenas) {
-            // evict the least recently used buffer (its stream may be gone: a synchronous free)
-            int lru = 0;
-            for (int i = 1; i < g_num_arenas; ++i)
-                if (g_arenas[i].last_use < g_arenas[lru].last_use) lru = i;
+            // evict the least recently used buffer that no graph holds (its stream may be gone: a synchronous free)
+            int lru = -1;
+            for (int i = 0; i < g_num_arenas; ++i)
+                if (!g_arenas[i].pinned && (lru < 0 || g_arenas[i].last_use < g_arenas[lru].last_use)) lru = i;
+            if (lru < 0) {   // every entry is pinned: nothing to cache this stream's buffer in
+                take_transient();
+                return L;
+            }
             int cur = dev;
             (void)hipSetDevice(g_arenas[lru].device);
             (void)hipFree(g_arenas[lru].ptr);
@@ -374,22 +406,24 @@ void* launcher_scratch(hipStream_t stream, size_t bytes, bool* transient, hipErr
             g_arenas[lru] = g_arenas[--g_num_arenas];
         }
         a = &g_arenas[g_num_arenas++];
-        *a = LauncherArena{dev, stream, nullptr, 0, 0};
+        *a = LauncherArena{dev, stream, nullptr, 0, 0, false};
     } else {
-        // grow: the old buffer goes back in stream order, behind the launches that still use it
-        if ((*err = hipFreeAsync(a->ptr, stream)) != hipSuccess) return nullptr;
+        // grow: the old buffer goes back in stream order, behind the launches that still use it (the lock is held
+        // by every caller until its launches are enqueued, so none of them can come after this free)
+        if ((L.err = hipFreeAsync(a->ptr, stream)) != hipSuccess) return L;
         a->ptr = nullptr;
         a->bytes = 0;
     }
     void* p = nullptr;
-    if ((*err = hipMallocAsync(&p, bytes, stream)) != hipSuccess) {
+    if ((L.err = hipMallocAsync(&p, bytes, stream)) != hipSuccess) {
         if (a->ptr == nullptr) *a = g_arenas[--g_num_arenas];  // drop the empty entry
-        return nullptr;
+        return L;
     }
     a->ptr = p;
     a->bytes = bytes;
     a->last_use = ++g_arena_clock;
-    return p;
+    L.ptr = p;
+    return L;
 }
 
 }  // namespace
@@ -1156,6 +1190,17 @@ int rroi_ctc_greedy_decode_hip(const float* logits, int num_seqs, int num_classe
     return launch_status();
 }
 
+int rroi_align_write_probe_hip(float* out, size_t num_floats, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!out || num_floats % 4 != 0 || reinterpret_cast<size_t>(out) % 16 != 0) return 0;
+    const size_t n4 = num_floats / 4;
+    if (n4 == 0) return 1;
+    if ((n4 + 255) / 256 >= (1ull << 31)) return 0;
+    hipLaunchKernelGGL(rroi_write_probe_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, out, n4);
+    return launch_status();
+}
+
 int rroi_align_set_trig_recipe_hip(int recipe)
 {
     if (recipe != RROI_TRIG_DOUBLE && recipe != RROI_TRIG_FP32) return 0;
@@ -1183,9 +1228,9 @@ int rroi_align_sincos_probe_hip(const float* angle_deg, int n, float* out, void*
 
 // ---- the reference's launcher ABI (rroi_align_kernel.h:8-18) ------------------------
 // The signatures carry no workspace (and the forward's no batch count), so the fast paths take
-// their scratch from the stream-ordered allocator: hipMallocAsync / hipFreeAsync on the caller's
-// stream, no synchronisation, nothing outlives the call.  Small problems keep the one-kernel
-// direct paths (no scratch).
+// their scratch from the library's per-(device, stream) buffers (launcher_scratch above: grown on
+// demand, reused by later calls, pinned once a graph has captured them; no synchronisation).
+// Small problems keep the one-kernel direct paths (no scratch).
 int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
                             const int num_rois, const int height, const int width,
                             const int channels, const int pooled_height, const int pooled_width,
@@ -1214,10 +1259,9 @@ int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
     // index as the reference does; a block whose ROI is of image 0 reads the index and leaves) and
     // skipped by the gather: the same two launches as the native call.
     const size_t bytes = carve(nullptr, 1, channels, height, width, num_rois, RROI_LAYOUT_NCHW).bytes;
-    bool transient;
-    hipError_t e;
-    void* ws = launcher_scratch(stream, bytes, &transient, &e);
-    if (!ws) return status_of(e);
+    ScratchLease lease = launcher_scratch(stream, bytes);
+    void* const ws = lease.ptr;
+    if (!ws) return status_of(lease.err);
     int st = forward_impl(bottom_data, RROI_LAYOUT_NCHW, RROI_LAYOUT_NCHW, spatial_scale, 1, num_rois, height,
                           width, channels, pooled_height, pooled_width, bottom_rois, top_data, ws, bytes,
                           RROI_PATH_TILED, RROI_STAGE_ALL, stream_, /*launcher_rest*/ true);
@@ -1226,7 +1270,7 @@ int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
                            num_rois, channels, height, width, pooled_height, pooled_width, spatial_scale, cslab);
         st = launch_status();
     }
-    if (transient) e = hipFreeAsync(ws, stream);
+    const hipError_t e = lease.give_back(stream);   // (everything that uses the buffer is enqueued)
     return st != 1 ? st : status_of(e);
 }
 
@@ -1250,14 +1294,13 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
     const int NB = pooled_height * pooled_width;
     if (pick_tiled_bwd(batch_size, channels, height, width, num_rois, NB)) {
         const size_t bytes = carve_bwd(nullptr, batch_size, channels, height, width, num_rois, NB).bytes;
-        bool transient;
-        hipError_t e;
-        void* ws = launcher_scratch(stream, bytes, &transient, &e);
-        if (!ws) return status_of(e);
+        ScratchLease lease = launcher_scratch(stream, bytes);
+        void* const ws = lease.ptr;
+        if (!ws) return status_of(lease.err);
         const int st = backward_impl(top_diff, RROI_LAYOUT_NCHW, RROI_LAYOUT_NCHW, spatial_scale, batch_size, num_rois,
                                      height, width, channels, pooled_height, pooled_width, bottom_rois, bottom_diff,
                                      ws, bytes, RROI_PATH_TILED, stream_, /*accumulate*/ true);
-        if (transient) e = hipFreeAsync(ws, stream);
+        const hipError_t e = lease.give_back(stream);
         return st != 1 ? st : status_of(e);
     }
     const long nthreads = (long)num_rois * pooled_height * pooled_width * channels;
@@ -1276,12 +1319,17 @@ int rroi_align_release_launcher_scratch(void)
     int cur = 0;
     (void)hipGetDevice(&cur);
     hipError_t e = hipSuccess;
+    int kept = 0;
     for (int i = 0; i < g_num_arenas; ++i) {
+        if (g_arenas[i].pinned) {   // a graph replays with this address: it lives as long as the process
+            g_arenas[kept++] = g_arenas[i];
+            continue;
+        }
         (void)hipSetDevice(g_arenas[i].device);
         const hipError_t ei = hipFree(g_arenas[i].ptr);  // synchronous: the buffers' streams may be gone
         if (ei != hipSuccess) e = ei;
     }
-    g_num_arenas = 0;
+    g_num_arenas = kept;
     (void)hipSetDevice(cur);
     return status_of(e);
 }

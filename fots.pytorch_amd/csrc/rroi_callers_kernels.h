@@ -174,3 +174,15 @@ __global__ void rroi_sincos_probe_kernel(const float* __restrict__ deg, int n, f
     out[2 * i + 1] = (float)sin((double)angle);
 }
 
+// ------------------------------------------------------------------------------------
+// Measurement hook (bench.py `roofline.calibrated_nonzero`): a plain write of NON-CONSTANT data,
+// one 16-byte store per thread -- the launch shape of a framework's elementwise kernel -- so that the ceiling of the
+// gather's output stream is measured in the same run, on the same box, by the same clock.  Not on the hot path.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rroi_write_probe_kernel(float* __restrict__ out, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n4) return;
+    const float f = (float)((unsigned)i * 2654435761u >> 8) * 1.1920929e-7f;   // [0, 2): a different value per store
+    reinterpret_cast<v4f*>(out)[i] = v4f{f, f + 1.0f, f * 3.0f, -f};
+}

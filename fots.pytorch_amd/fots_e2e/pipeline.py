@@ -4,16 +4,17 @@
       --net--> score, rbox, angle maps (1/4) and features [merged 256 ch, focr 64 ch]
       --boxes--> (N, 9) quads + score   (`nms.get_boxes`; rroi_align.nms here, or a seeded synthetic
                                           set while the detection heads carry random weights)
-      --recognise--> N strings          two implementations with identical results:
+      --recognise--> N strings
 
-  per_box   the reference's structure, `tools/ocr_utils.py:131-199` per word: ROI built on the host
-            (Python floats), uploaded, `_RRoiAlign(11, target_gw, 1/4)` with R = 1, `forward_ocr`,
-            `max(1)`, `decode`: ~6 launches + 1 upload + 1 read-back per WORD;
   batched   ROI rows of all boxes built on the device (`rroi_align_quads_to_rois_hip`), ONE RoIRotate
             launch per image at the widest pooled width, `forward_ocr` once per width BUCKET on the
             crops' own first target_gw columns (InstanceNorm statistics are per sample and per
             width, so a word must see exactly the columns the per-box call gives it), one batched
             greedy-CTC launch per bucket: per IMAGE a handful of launches and one read-back.
+
+The reference's own structure (`tools/ocr_utils.py:131-199`: per WORD a host-built ROI, an upload, an R = 1
+launch, the head, `max(1)`, a Python decode) is not part of this package: it lives with the checkers
+(`oracle/e2e_loop_oracle.py`), where the tests compare the two and `bench_e2e.py` times it as the baseline.
 """
 import math
 
@@ -99,41 +100,24 @@ def synthetic_detector_maps(height, width, nwords, seed=0):
     return segm, geo, ang
 
 
-def host_roi(box):
-    """One box -> ([0, int(cx), int(cy), h, w, angle], target_gw) as `align_ocr` computes them on
-    the host (tools/ocr_utils.py:133-150): numpy fp32 corner arithmetic, Python-float sqrt/atan2."""
-    b = np.asarray(box[0:8], np.float32).reshape(-1, 2)
-    center = (b[0, :] + b[1, :] + b[2, :] + b[3, :]) / 4
-    dw, dh = b[2, :] - b[1, :], b[1, :] - b[0, :]
-    w = math.sqrt(dw[0] * dw[0] + dw[1] * dw[1])
-    h = math.sqrt(dh[0] * dh[0] + dh[1] * dh[1])
-    angle = -math.atan2(b[2][1] - b[1][1], b[2][0] - b[1][0]) / 3.1415926535 * 180
-    gw = int(w * (TARGET_H / max(1, h))) + TARGET_H
-    return [0, int(center[0]), int(center[1]), h, w, angle], max(2, gw // 32) * 32
-
-
-def per_box(net, converter, features, boxes, return_crops=False):
-    """The reference's loop (test.py:102-116): one word at a time.  -> texts[, crops, labels]"""
-    focr = features[1]
-    texts, crops, labels = [], [], []
-    for box in boxes:
-        roi, gw = host_roi(box)
-        rois = torch.tensor(roi).to(torch.float).to(focr.device)
-        x = _RRoiAlign(TARGET_H, gw, SPATIAL_SCALE)(focr, rois.view(-1, 6))
-        logp = net.forward_ocr(x)
-        _, lab = logp.max(1)
-        lab = lab.transpose(1, 0).contiguous().view(-1)
-        texts.append(converter.decode(lab.cpu(), torch.IntTensor([lab.size(0)]), raw=False))
-        if return_crops:
-            crops.append(x)
-            labels.append(lab)
-    return (texts, crops, labels) if return_crops else texts
+def target_widths_host(boxes):
+    """The callers' pooled-width rule (tools/ocr_utils.py:146-150) for boxes that are already on the host:
+    target_gw = int(w * (11 / max(1, h))) + 11 rounded down to a multiple of 32, at least 64 -- w, h from the fp32
+    corner differences, square root in double.  The same numbers the device kernel
+    (`rroi_align_quads_to_rois_hip`, mode 0) writes next to its ROI rows (asserted equal in
+    tests/test_e2e_gpu.py); having them here saves `infer_image` a read-back before the head."""
+    b = np.asarray(boxes, np.float32)[:, :8].reshape(-1, 4, 2)
+    dw, dh = b[:, 2] - b[:, 1], b[:, 1] - b[:, 0]
+    w = np.sqrt((dw[:, 0] * dw[:, 0] + dw[:, 1] * dw[:, 1]).astype(np.float64))
+    h = np.sqrt((dh[:, 0] * dh[:, 0] + dh[:, 1] * dh[:, 1]).astype(np.float64))
+    gw = (w * (TARGET_H / np.maximum(1.0, h))).astype(np.int64) + TARGET_H
+    return (np.maximum(2, gw // 32) * 32).tolist()
 
 
 def batched(net, converter, features, boxes, return_crops=False, gw_host=None):
     """All words of an image at once.  `boxes`: (N, >= 8) tensor on the device (or array).
     `gw_host`: the boxes' pooled widths when the caller already has them on the host (`infer_image`:
-    the boxes come out of the host-side merge, and the width rule is `host_roi`'s) -- then nothing is
+    the boxes come out of the host-side merge: `target_widths_host`) -- then nothing is
     read back before the head."""
     focr = features[1]
     quads = torch.as_tensor(boxes, dtype=torch.float32, device=focr.device)[:, :8].contiguous()
@@ -171,7 +155,7 @@ def batched(net, converter, features, boxes, return_crops=False, gw_host=None):
     return (texts, crops, labels) if return_crops else texts
 
 
-def infer_image(net, converter, im, detector=None, segm_thresh=0.5, recognise="batched", return_debug=False):
+def infer_image(net, converter, im, detector=None, segm_thresh=0.5, return_debug=False):
     """One image through the whole chain of `test.py:75-116`: preprocess -> net -> `get_boxes` on the maps
     where the network wrote them -> RoIRotate + recognition head + greedy CTC for every box ->
     (boxes (n, 9) numpy, texts); like the reference's loop, boxes whose text is empty are dropped
@@ -180,12 +164,11 @@ def infer_image(net, converter, im, detector=None, segm_thresh=0.5, recognise="b
     `detector`: optional hook `im_data -> (score (h, w), rbox (4, h, w), angle (2, h, w))` device tensors
     that stand in for the three head outputs -- random weights pass no box (or a hundred thousand)
     through the NMS, so tests and the benchmark inject `synthetic_detector_maps` here.
-    `recognise`: "batched" (the MI355X shape) or "per_box" (the reference's loop, kept as the checker).
 
-    Host synchronisations per image on the batched path: ONE before the head (`get_boxes` reads the
-    number of passing pixels and their records: the merge is sequential host code) and the final
-    read-back of the decoded labels.  The pooled-width buckets need no second one: the boxes are on
-    the host after the merge and the width rule is plain arithmetic (`host_roi`)."""
+    Host synchronisations per image: ONE before the head (`get_boxes` reads the number of passing pixels
+    and their records: the merge is sequential host code) and the final read-back of the decoded labels.
+    The pooled-width buckets need no second one: the boxes are on the host after the merge and the width
+    rule is plain arithmetic (`target_widths_host`)."""
     from rroi_align.nms import get_boxes
     device = next(net.parameters()).device
     im_data = preprocess(im, device) if not isinstance(im, torch.Tensor) else im
@@ -195,11 +178,7 @@ def infer_image(net, converter, im, detector=None, segm_thresh=0.5, recognise="b
     else:
         s, r, a = score[0][0, 0], rbox[0][0], angle[0][0]
     boxes = get_boxes(s, r, a, segm_thresh)
-    if recognise == "per_box":
-        out = per_box(net, converter, feats, boxes, return_crops=return_debug)
-    else:
-        gw = [host_roi(b)[1] for b in boxes]
-        out = batched(net, converter, feats, boxes, return_crops=return_debug, gw_host=gw)
+    out = batched(net, converter, feats, boxes, return_crops=return_debug, gw_host=target_widths_host(boxes))
     texts = out[0] if return_debug else out
     keep = [i for i, t in enumerate(texts) if len(t) > 0]
     res = (boxes[keep], [texts[i] for i in keep])

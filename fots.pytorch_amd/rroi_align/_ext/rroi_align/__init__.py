@@ -71,6 +71,8 @@ _lib.rroi_ctc_greedy_decode_hip.restype = _i
 _lib.rroi_ctc_greedy_decode_hip.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.rroi_align_sincos_probe_hip.restype = _i
 _lib.rroi_align_sincos_probe_hip.argtypes = [_vp, _i, _vp, _vp]
+_lib.rroi_align_write_probe_hip.restype = _i
+_lib.rroi_align_write_probe_hip.argtypes = [_vp, _sz, _vp]
 _lib.rroi_align_set_trig_recipe_hip.restype = _i
 _lib.rroi_align_set_trig_recipe_hip.argtypes = [_i]
 _lib.rroi_align_get_trig_recipe_hip.restype = _i
@@ -90,6 +92,7 @@ EXPORTS = (
     "rroi_ctc_greedy_decode_hip", "rroi_align_backward_layout_hip", "rroi_align_forward_layout_hip",
     "rroi_align_gt_quads_to_rois_hip", "rroi_rbox_decode_hip", "rroi_nms_merge_host",
     "rroi_align_release_launcher_scratch", "rroi_align_set_trig_recipe_hip", "rroi_align_get_trig_recipe_hip",
+    "rroi_align_write_probe_hip",
 )
 
 

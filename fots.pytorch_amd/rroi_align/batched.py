@@ -45,7 +45,7 @@ class GroundTruthRRoiAlign(Module):
     """The training caller's call (src/ocr_process.py:196-221, :253-267): ground-truth quads of a
     batch -> crops for the recognition loss, ROI rows and pooled width computed on the device.
 
-    forward(features, quads, batch_index, height_jitter=None, keep=None)
+    forward(features, quads, batch_index, height_jitter=None, keep=None, per_image_jitter=None)
         -> (crops (N, C, pooled_height, pooled_width), rois)
     with pooled_width = ceil(pooled_height * max(w / h)) (:260-263) read back once, as the
     reference does with `.item()`.
@@ -56,7 +56,9 @@ class GroundTruthRRoiAlign(Module):
     with `keep` (N,) bool: the filter is applied first, `max_rois` second -- the reference's order.
     `height_jitter` is the caller's random.randint(-2, 2) (:204): one value per box, or -- what the
     reference draws -- ONE PER IMAGE, a tensor of batch-size length that is then looked up through
-    `batch_index`.  Rows whose jittered h is negative yield all-zero crops (the op's
+    `batch_index`.  Which of the two it is is SAID, not guessed: `per_image_jitter=True` / `False`; left at None
+    the length decides only while it can (a length that equals both the number of boxes and could be a batch
+    size -- e.g. one box per image -- raises instead of silently taking one reading).  Rows whose jittered h is negative yield all-zero crops (the op's
     `pw <= roi_pooled_width` mask is false everywhere, kernel.cu:107); an h of exactly 0 makes the ratio
     infinite -- the reference's `math.ceil` raises there, and so does this module.  A maximal ratio
     <= 0 (every w = 0) would make the reference's pooled width 0 (and its launch fail); it is 1 here.
@@ -68,13 +70,25 @@ class GroundTruthRRoiAlign(Module):
         self.spatial_scale = float(spatial_scale)
         self.max_rois = max_rois
 
-    def forward(self, features, quads, batch_index=None, height_jitter=None, keep=None):
+    def forward(self, features, quads, batch_index=None, height_jitter=None, keep=None, per_image_jitter=None):
         import math
         n = quads.shape[0]
-        if height_jitter is not None and height_jitter.numel() != n:
-            if batch_index is None:
-                raise ValueError("a per-image height_jitter needs batch_index")
-            height_jitter = height_jitter.reshape(-1)[batch_index.reshape(-1).long()]
+        if height_jitter is not None:
+            m = height_jitter.numel()
+            if per_image_jitter is None:
+                # the length tells only when it cannot be read both ways
+                if m == n and batch_index is not None and m == features.shape[0] and n > 1:
+                    raise ValueError("height_jitter has one entry per box AND one per image (%d): say which with "
+                                     "per_image_jitter=True / False" % m)
+                per_image_jitter = m != n
+            if per_image_jitter:
+                if batch_index is None:
+                    raise ValueError("a per-image height_jitter needs batch_index")
+                if m != features.shape[0]:
+                    raise ValueError("per-image height_jitter: %d entries for %d images" % (m, features.shape[0]))
+                height_jitter = height_jitter.reshape(-1)[batch_index.reshape(-1).long()]
+            elif m != n:
+                raise ValueError("per-box height_jitter: %d entries for %d boxes" % (m, n))
         if keep is not None:
             keep = keep.reshape(-1).bool()
             quads = quads[keep]

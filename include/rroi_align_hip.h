@@ -55,8 +55,15 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
 
 /* The two launchers above carry no workspace argument: the library keeps one scratch buffer per
  * (device, stream), grown on demand and reused by later calls on that stream (no allocation per call;
- * a call whose buffer exists only enqueues kernels and can be captured into a HIP graph).  This frees
- * all of them (synchronously); they are re-created on demand.  Returns 1 / -hipError. */
+ * a call whose buffer exists only enqueues kernels and can be captured into a HIP graph).
+ * Lifetime: a buffer handed out while its stream was CAPTURING is part of a graph and is never freed
+ * afterwards -- a later, larger call on that stream takes stream-ordered memory for itself, the
+ * least-recently-used eviction (16 buffers are kept) passes it over, and the function below leaves it
+ * alone -- so a captured launcher call stays replayable for the life of the process.  To capture with
+ * memory the GRAPH owns instead, capture the first call on a stream that has no buffer yet (or one
+ * that is too small): that call allocates inside the capture.
+ * This frees every buffer no graph holds (synchronously); they are re-created on demand.
+ * Returns 1 / -hipError. */
 int rroi_align_release_launcher_scratch(void);
 
 /* ------------------------------------------------------------------------- *
@@ -77,15 +84,20 @@ int rroi_align_release_launcher_scratch(void);
 #define RROI_PATH_TILED_ATOMIC 3 /* backward only: the tiled scatter with fp32 atomics (the
                                     default tiled backward is an atomic-free gather)         */
 #define RROI_PATH_TILED_LISTS 4  /* backward only: the gather over per-pixel lists built in HBM by
-                                    count / scan / fill launches (what TILED runs where the memory
-                                    cap leaves a bucket below the mean list)                 */
+                                    count / scan / fill launches.  AUTO / TILED fall back to it where
+                                    the memory cap leaves a bucket below the mean list, unless the
+                                    in-kernel gather's rule (below) takes the problem         */
 #define RROI_PATH_TILED_BUCKETS 6 /* backward only (round 3): the gather over per-pixel lists built in ONE pass --
                                     fixed-capacity buckets per pixel plus overflow chains: no count pass, no
                                     scan.  What AUTO / TILED run (the bucket grows with the density, 16 ..
                                     4096 entries, under a memory cap); any density is accepted when named    */
 #define RROI_PATH_TILED_INKERNEL 5 /* backward only: the gather that finds each map tile's bins
-                                    inside the kernel, no lists in HBM (only when named; round 2's
-                                    choice for C <= 64)                                       */
+                                    inside the kernel, no lists in HBM.  Round 2's choice for C <= 64;
+                                    since round 3 AUTO / TILED reach it only where the buckets are not
+                                    to be had (capped below the mean list, or 32-bit bucket indices
+                                    exceeded) AND its own rule holds: at most two channel chunks per
+                                    lane, or four with <= 8 bins per map pixel, or eight with <= 1, and
+                                    R x B <= 8192.  Named, it runs wherever its 32-bit offsets hold   */
 
 /* Bytes of scratch the tiled path needs for this problem (0 for the direct
  * path).  The caller owns the scratch; its contents are dead after the call. */
@@ -222,6 +234,11 @@ int rroi_align_bin_centres_hip(float spatial_scale, int num_rois, int height, in
  * through the same device code the kernels use (test hook for the one
  * library-dependent step of the arithmetic recipe). out = (n, 2). */
 int rroi_align_sincos_probe_hip(const float* angle_deg, int n, float* out, void* stream);
+
+/* Measurement hook: fills out[0 .. num_floats) (16-byte aligned, a multiple of 4 floats) with values that differ
+ * from store to store, one 16-byte plain store per thread.  bench.py times it on the output buffer as the ceiling
+ * a write of non-zero, non-constant data reaches on the box (zeros are written faster on this chip). */
+int rroi_align_write_probe_hip(float* out, size_t num_floats, void* stream);
 
 /* The one library-dependent step of the arithmetic (rroi_align_kernel.cu:73-74, `cos(angle)` / `sin(angle)` of a
  * float).  RROI_TRIG_DOUBLE (default): (float)cos((double)angle), the recipe of the oracle -- bit-exact against it

@@ -346,6 +346,68 @@ void rroi_oracle_backward(const float* top_diff, float spatial_scale, int batch_
     free(acc);
 }
 
+/*
+ * The same hoisted backward on `threads` OpenMP threads (the CPU baseline of bench.py's backward leg,
+ * BASELINE.md section 2 last row).  A thread owns the channels c = tid, tid + T, ...: no two threads touch the same
+ * feature element, and every element still receives its contributions in the order (n, ph, pw) ascending, in
+ * double -- the result is bit-identical to rroi_oracle_backward whatever the thread count.  Per ROI every thread
+ * tabulates the bins' taps once (512 bins at 8 x 64) and then walks its channels with top_diff read contiguously.
+ */
+void rroi_oracle_backward_mt(const float* top_diff, float spatial_scale, int batch_size, int num_rois,
+                             int height, int width, int channels, int pooled_height,
+                             int pooled_width, const float* bottom_rois, float* bottom_diff, int threads)
+{
+    const long plane_sz = (long)height * width;
+    const long total = (long)batch_size * channels * plane_sz;
+    const long bins = (long)pooled_height * pooled_width;
+    double* acc = (double*)calloc((size_t)total, sizeof(double));
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        const int tid = 0, nt = 1;
+#endif
+        int* off = (int*)malloc((size_t)bins * 4 * sizeof(int));     /* pixel index of each tap, -1: fails :267-274 */
+        float* wgt = (float*)malloc((size_t)bins * 4 * sizeof(float));
+        for (int n = 0; n < num_rois; ++n) {
+            rroi_affine_t A;
+            rroi_oracle_affine(bottom_rois + (long)n * 6, pooled_height, spatial_scale, &A);
+            for (int ph = 0; ph < pooled_height; ++ph)
+                for (int pw = 0; pw < pooled_width; ++pw) {
+                    const long b = (long)ph * pooled_width + pw;
+                    float bin_cx, bin_cy;
+                    off[4 * b] = off[4 * b + 1] = off[4 * b + 2] = off[4 * b + 3] = -1;
+                    if (!bin_centre(&A, ph, pw, height, width, &bin_cx, &bin_cy)) continue;
+                    tap_weights(bin_cx, bin_cy, &wgt[4 * b], &wgt[4 * b + 1], &wgt[4 * b + 2], &wgt[4 * b + 3]);
+                    const int min_x = f2i_sat(floorf(bin_cx)), max_x = f2i_sat(ceilf(bin_cx));
+                    const int min_y = f2i_sat(floorf(bin_cy)), max_y = f2i_sat(ceilf(bin_cy));
+                    if (min_y > 0 && min_x > 0 && min_y < height - 1 && min_x < width - 1) off[4 * b] = min_y * width + min_x;
+                    if (min_y > 0 && max_x < width - 1 && min_y < height - 1 && max_x > 0) off[4 * b + 1] = min_y * width + max_x;
+                    if (max_y < height - 1 && max_x < width - 1 && max_y > 0 && max_x > 0) off[4 * b + 2] = max_y * width + max_x;
+                    if (max_y < height - 1 && min_x > 0 && max_y > 0 && min_x < width - 1) off[4 * b + 3] = max_y * width + min_x;
+                }
+            for (int c = tid; c < channels; c += nt) {
+                const float* g = top_diff + ((long)n * channels + c) * bins;
+                double* plane = acc + ((long)A.batch * channels + c) * plane_sz;
+                for (long b = 0; b < bins; ++b) {
+                    const int* o = off + 4 * b;
+                    const float* w = wgt + 4 * b;
+                    if (o[0] >= 0) plane[o[0]] += (double)(w[0] * g[b]);
+                    if (o[1] >= 0) plane[o[1]] += (double)(w[1] * g[b]);
+                    if (o[2] >= 0) plane[o[2]] += (double)(w[2] * g[b]);
+                    if (o[3] >= 0) plane[o[3]] += (double)(w[3] * g[b]);
+                }
+            }
+        }
+        free(off);
+        free(wgt);
+    }
+    for (long i = 0; i < total; ++i) bottom_diff[i] = (float)acc[i];
+    free(acc);
+}
+
 /* Number of distinct feature elements the forward reads (for bytes_feat in
  * SURVEY.md section 8(d)): counts (batch, y, x) taps that pass the validity
  * test of at least one active bin; multiply by channels*4 for bytes. */

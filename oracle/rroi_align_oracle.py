@@ -111,15 +111,21 @@ def backward_literal_c(grad_out, rois, idx_x, idx_y, feat_shape, scale):
     return gin
 
 
-def backward_c(grad_out, rois, feat_shape, scale):
-    """Hoisted backward, double accumulation (order-free reference value)."""
+def backward_c(grad_out, rois, feat_shape, scale, threads=None):
+    """Hoisted backward, double accumulation (order-free reference value).  threads=None: the single-threaded
+    statement-order form; threads=T: the channel-partitioned OpenMP form (bit-identical result; bench.py's
+    CPU baseline for the backward)."""
     B, C, H, W = feat_shape
     grad_out = np.ascontiguousarray(grad_out, np.float32)
     rois = np.ascontiguousarray(rois, np.float32).reshape(-1, 6)
     R, _, PH, PW = grad_out.shape
     gin = np.empty(feat_shape, np.float32)
-    lib().rroi_oracle_backward(_p(grad_out), ctypes.c_float(scale), B, R, H, W, C, PH, PW,
-                               _p(rois), _p(gin))
+    if threads is None:
+        lib().rroi_oracle_backward(_p(grad_out), ctypes.c_float(scale), B, R, H, W, C, PH, PW,
+                                   _p(rois), _p(gin))
+    else:
+        lib().rroi_oracle_backward_mt(_p(grad_out), ctypes.c_float(scale), B, R, H, W, C, PH, PW,
+                                      _p(rois), _p(gin), int(threads))
     return gin
 
 

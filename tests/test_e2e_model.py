@@ -10,7 +10,8 @@ import torch
 
 from fots_e2e.alphabet import ALPHABET
 from fots_e2e.model import FOTSNet
-from fots_e2e.pipeline import host_roi, resize_rule, synthetic_boxes
+from fots_e2e.pipeline import resize_rule, synthetic_boxes, target_widths_host
+from oracle.e2e_loop_oracle import host_roi
 from fots_e2e.weights import deterministic_init
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_model.npz")
@@ -74,4 +75,6 @@ def test_host_roi_is_the_callers_rule():
     assert roi[5] == -math.atan2(-35, 150) / 3.1415926535 * 180
     assert gw == max(2, (int(w * (11 / h)) + 11) // 32) * 32 == 96
     b = synthetic_boxes(50, 704, 1280, seed=1)
+    # the product's vectorised width rule gives the per-word rule's widths
+    assert target_widths_host(b) == [host_roi(x)[1] for x in b] and target_widths_host(box[None]) == [96]
     assert b.shape == (50, 9) and (b[:, :8] >= 0).all() and (b[:, 0:8:2] <= 1280).all() and (b[:, 1:8:2] <= 704).all()

@@ -491,7 +491,34 @@ def test_reference_launchers_reuse_their_scratch_and_accumulate(ext, oracle):
     torch.cuda.synchronize()
     assert torch.equal(out, want_out)
     assert float((gin - g1).abs().max()) <= BWD_RTOL * max(1.0, float(g1.abs().max()))
-    ext.release_workspaces()            # frees the library's buffers too; the next call re-creates them
+    # the buffer the capture was handed is PINNED.  A later, larger call on the same stream (rounds 2-3
+    # freed the small buffer in stream order to grow it), the release call and more streams than the table holds
+    # all leave it alone: the graph replays correctly afterwards
+    f2, r2 = Wk.bench_inputs(R=384, C=64, seed=33)
+    F2, R2 = dev(f2), dev(r2)
+    big = torch.empty((384, 64, 8, 64), device="cuda")
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            assert ext._lib.RROIAlignForwardLaucher(F2.data_ptr(), 0.25, 384, 160, 160, 64, 8, 64, R2.data_ptr(),
+                                                    big.data_ptr(), None, None, side.cuda_stream) == 1
+        side.synchronize()
+    assert eq(big.cpu().numpy(), oracle.forward_c(f2, r2, 8, 64, 0.25))
+    others = [torch.cuda.Stream() for _ in range(18)]          # more streams than the library keeps buffers for
+    for s_ in others:
+        with torch.cuda.stream(s_):
+            assert ext._lib.RROIAlignForwardLaucher(F.data_ptr(), 0.25, 96, 160, 160, 64, 8, 64, Rr.data_ptr(),
+                                                    big.data_ptr(), None, None, s_.cuda_stream) == 1
+    torch.cuda.synchronize()
+    ext.release_workspaces()
+    scribble = [torch.full((64 << 18,), float("nan"), device="cuda") for _ in range(4)]   # reuse what was freed
+    out.zero_()
+    gin.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    del scribble
+    assert torch.equal(out, want_out)
+    assert float((gin - g1).abs().max()) <= BWD_RTOL * max(1.0, float(g1.abs().max()))
+    ext.release_workspaces()            # frees the library's unpinned buffers too; the next call re-creates them
     assert ext._lib.RROIAlignForwardLaucher(F.data_ptr(), 0.25, 96, 160, 160, 64, 8, 64, Rr.data_ptr(),
                                             out.data_ptr(), None, None, stream()) == 1
     torch.cuda.synchronize()

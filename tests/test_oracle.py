@@ -120,3 +120,15 @@ def test_touched_pixels_matches_survey(oracle):
     _, r = Wk.bench_inputs(R=512, C=1)
     n = oracle.touched_pixels(r, 1, 160, 160, 8, 64, 0.25)
     assert 0.95 * 25600 < n <= 159 * 159
+
+
+def test_threaded_backward_is_bit_identical_to_the_statement_order_form(oracle):
+    """bench.py's CPU baseline for the backward: channel-partitioned OpenMP, same accumulation order per
+    feature element -> the same bits for every thread count."""
+    import workloads as Wk
+    f, r = Wk.bench_inputs(R=24, C=13, H=40, W=56, img=224, seed=3, batch=2)
+    rng = np.random.default_rng(0)
+    g = rng.standard_normal((24, 13, 8, 32), dtype=np.float32)
+    want = oracle.backward_c(g, r, f.shape, 0.25)
+    for t in (1, 3, 8):
+        assert np.array_equal(oracle.backward_c(g, r, f.shape, 0.25, threads=t), want), t

@@ -77,6 +77,20 @@ __global__ __launch_bounds__(256) void k_store_linear256(float* __restrict__ out
     }
 }
 
+// ---- write ceiling (round 4): ONE float4 per thread, torch's elementwise launch shape; DATA 0 zeros, 1 a non-zero
+// constant, 2 values that depend on the index; AUX cache policy of the store (0 plain, 2 nt, 16 sc1, 17 sc0 sc1)
+template <int DATA, int AUX>
+__global__ __launch_bounds__(256) void k_store_once(float* __restrict__ out, unsigned n4)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n4) return;
+    const float f = DATA == 2 ? (float)(i * 2654435761u >> 8) * 1.1920929e-7f : DATA == 1 ? 1.0f : 0.0f;
+    const v4f v = {f, DATA == 2 ? f + 1.0f : f, DATA == 2 ? f * 3.0f : f, DATA == 2 ? -f : f};
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(out, 0xffffffffu);
+    if (AUX == 0) reinterpret_cast<v4f*>(out)[i] = v;
+    else if ((size_t)i * 16 < 0xffffffffull) buf_store<AUX>(rs, i * 16u, v);
+}
+
 // ---- raw L2->CU gather bandwidth: every lane group of LPG lanes reads one contiguous run of
 // LPG*16 bytes at a pseudo-random offset inside `region_bytes`; DEPTH independent loads in
 // flight per wave.  LPG = 64: 1 KiB contiguous per instruction; 8: eight 128 B lines; 1: 64 x 16 B.
@@ -357,6 +371,24 @@ int main(int argc, char** argv)
                 snprintf(nm, 96, "rep %d early=%d: whole step, 50 x 20 steps", rep, e);
                 report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 50, 5) / 20, MB);
             }
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "wceil") {
+        // what a plain write of 256 MiB reaches on this box, by data and by store policy (profiles/r04_write_ceiling.txt)
+        const unsigned n4 = (unsigned)((size_t)R * C * NB / 4);
+        const unsigned blocks = (n4 + 255) / 256;
+        for (int rep = 0; rep < 3; ++rep) {
+            report("hipMemsetAsync 0x00", T.us([&] { CK(hipMemsetAsync(out, 0, (size_t)n4 * 16, 0)); }, 100), MB);
+            report("hipMemsetAsync 0x3f", T.us([&] { CK(hipMemsetAsync(out, 0x3f, (size_t)n4 * 16, 0)); }, 100), MB);
+            report("one float4 per thread, zeros, plain", T.us([&] { hipLaunchKernelGGL((k_store_once<0, 0>), dim3(blocks), dim3(256), 0, 0, out, n4); }, 100), MB);
+            report("one float4 per thread, constant 1.0, plain", T.us([&] { hipLaunchKernelGGL((k_store_once<1, 0>), dim3(blocks), dim3(256), 0, 0, out, n4); }, 100), MB);
+            report("one float4 per thread, index-dependent values, plain", T.us([&] { hipLaunchKernelGGL((k_store_once<2, 0>), dim3(blocks), dim3(256), 0, 0, out, n4); }, 100), MB);
+            report("one float4 per thread, index-dependent values, nt", T.us([&] { hipLaunchKernelGGL((k_store_once<2, 2>), dim3(blocks), dim3(256), 0, 0, out, n4); }, 100), MB);
+            report("one float4 per thread, index-dependent values, sc1", T.us([&] { hipLaunchKernelGGL((k_store_once<2, 16>), dim3(blocks), dim3(256), 0, 0, out, n4); }, 100), MB);
+            report("one float4 per thread, index-dependent values, sc0 sc1", T.us([&] { hipLaunchKernelGGL((k_store_once<2, 17>), dim3(blocks), dim3(256), 0, 0, out, n4); }, 100), MB);
+            report("grid-stride 256-thread blocks, constant, plain", T.us([&] { hipLaunchKernelGGL((k_store_linear256<1>), dim3(256 * 8), dim3(256), 0, 0, out, (size_t)n4); }, 100), MB);
+            report("the gather's tile pattern, 1/8 sc0sc1 + nt (what ships)", T.us([&] { hipLaunchKernelGGL((k_store_mix<0, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 8); }, 100), MB);
+        }
         return 0;
     }
     if (argc > 1 && std::string(argv[1]) == "stmix") {
