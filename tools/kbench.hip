@@ -255,6 +255,27 @@ __global__ __launch_bounds__(64) void k_xcd_probe(unsigned* rec, unsigned* cnt, 
     }
 }
 
+// ---- returning counter atomics (round 4): does it matter whether the counters a workgroup hits are
+// also hit from other XCDs?  Every wave instruction adds 1 to the 32 counters of `lines` random 128-byte lines
+// (lines = 1: all 64 lanes on one line, two lanes per counter; 8: eight lanes per line -- the pair pass sees 2-6).
+// LOCAL = 0: one counter array for the chip; 1: an array per block % 8 (= per XCD); NORET: fire and forget.
+template <int LOCAL, int NORET>
+__global__ __launch_bounds__(256) void k_counter_atomics(unsigned* cnt, unsigned* sink, unsigned nlines, unsigned lines, unsigned iters)
+{
+    const unsigned lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    unsigned* base = cnt + (LOCAL ? (size_t)(blockIdx.x % 8u) * nlines * 32u : 0u);
+    unsigned h = wave * 2654435761u + 12345u, acc = 0;
+    const unsigned per = 64u / lines;           // lanes per line
+    for (unsigned i = 0; i < iters; ++i) {
+        h = h * 1664525u + 1013904223u;
+        const unsigned line = ((h >> 8) + (lane / per) * 7919u) % nlines;
+        unsigned* p = base + (size_t)line * 32u + (lane % per) % 32u;
+        if (NORET) atomicAdd(p, 1u);
+        else acc += atomicAdd(p, 1u);
+    }
+    if (!NORET && acc == 0xdeadbeefu) sink[0] = acc;
+}
+
 struct Timer {
     hipEvent_t a, b;
     Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
@@ -371,6 +392,27 @@ int main(int argc, char** argv)
                 snprintf(nm, 96, "rep %d early=%d: whole step, 50 x 20 steps", rep, e);
                 report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 50, 5) / 20, MB);
             }
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "xatom") {
+        const unsigned nlines = 3200;   // 160 x 160 map in 8 x 4 key tiles = 800 lines per image; x4 for spread
+        unsigned *cnt, *sink;
+        CK(hipMalloc(&cnt, (size_t)8 * nlines * 128));
+        CK(hipMalloc(&sink, 64));
+        CK(hipMemset(cnt, 0, (size_t)8 * nlines * 128));
+        const unsigned iters = 64, blocks = 256 * 4;
+        const double atom = (double)blocks * 256 * iters;
+        for (unsigned lines : {1u, 2u, 4u, 8u, 16u, 64u}) {
+            for (int rep = 0; rep < 2; ++rep) {
+                const double a = T.us([&] { hipLaunchKernelGGL((k_counter_atomics<0, 0>), dim3(blocks), dim3(256), 0, 0, cnt, sink, nlines, lines, iters); }, 20, 3);
+                const double b = T.us([&] { hipLaunchKernelGGL((k_counter_atomics<1, 0>), dim3(blocks), dim3(256), 0, 0, cnt, sink, nlines, lines, iters); }, 20, 3);
+                const double c = T.us([&] { hipLaunchKernelGGL((k_counter_atomics<0, 1>), dim3(blocks), dim3(256), 0, 0, cnt, sink, nlines, lines, iters); }, 20, 3);
+                const double d = T.us([&] { hipLaunchKernelGGL((k_counter_atomics<1, 1>), dim3(blocks), dim3(256), 0, 0, cnt, sink, nlines, lines, iters); }, 20, 3);
+                printf("lines/instr %2u: returning shared %8.1f us (%6.2f G lane-atomics/s, %6.2f G line-requests/s) | per-XCD arrays %8.1f us (%6.2f, %6.2f) | no-return shared %8.1f us, per-XCD %8.1f us\n",
+                       lines, a, atom / a / 1e3, atom / 64 * lines / a / 1e3, b, atom / b / 1e3, atom / 64 * lines / b / 1e3, c, d);
+                fflush(stdout);
+            }
+        }
         return 0;
     }
     if (argc > 1 && std::string(argv[1]) == "wceil") {
