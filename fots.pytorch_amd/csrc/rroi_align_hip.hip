@@ -13,10 +13,11 @@
 // the hot path first relays the map out CHUNK-MAJOR: (B, C/32, H*W+1, 32) --
 // 32 channels of a pixel are one 128-byte line, consecutive pixels of a chunk
 // are consecutive lines (all L2 channels of an XCD are used evenly), and every
-// (image, chunk) slice ends in a zero pixel that invalid taps point at.  Each
-// wave then owns a [32 channel] x [64 bin] output tile: lanes = 8 bins x 8
+// (image, chunk) slice is one buffer descriptor, whose range check turns invalid
+// taps into 0.0.  A workgroup (a gatherer and a storer wave) then owns a
+// [32 channel] x [64 bin] output tile at a time: lanes = 8 bins x 8
 // channel-quads fetch taps as 16-byte loads, blend in the reference's order,
-// transpose through a wave-private LDS tile and stream the tile out as full
+// transpose through an LDS tile, and the tile streams out as full
 // 256-byte row segments of the (R,C,PH,PW) tensor.  Channel chunk k is handled
 // by blocks with blockIdx % nchunks == k, i.e. (8 chunks at C=256) by one XCD,
 // whose 4 MiB L2 then holds exactly its 3.2 MB slice of the map.
@@ -75,13 +76,40 @@ int num_cus()
     return cus;
 }
 
+// Launch-shape constants of the shipped configuration.  The product reads them as compile-time constants; the
+// exploration build (-DRROI_EXPLORE: tools/kbench.hip, tools/build_explore.sh) makes the struct mutable and adds the
+// rroi_align_debug_set_* setters of tools/rroi_explore_setters.h -- none of that is in the product library.
+struct Tuning {
+    int row_pad = -1;             // chunk-major row pitch: -1 = W | 1 (see row_pitch)
+    int waves_per_cu = 12;        // one-wave tiled kernels (the backward's atomic scatter): 12.4 KB of LDS each
+    // rroi_fwd_split_kernel: 62-64 VGPRs under __launch_bounds__(128, 6) and 12.1 KB of LDS (10 granules of 1280 B)
+    // -> 12 workgroups per CU; a larger grid would run its surplus as a second round
+    int split_wgs_per_cu = 12;
+    int fwd_shift = 1;            // 1: crops with PH * PW % 16 != 0 take the SHIFT forms where they pay; 2: always; 0: never
+    int shift_pre = 1;            // SHIFT = 1: runs that start inside a block begin with a pre item
+    int shift_parts = 0;          // > 0 forces the runs per (roi, chunk) block
+    int shift_wgs_per_cu = 0;     // > 0 overrides the SHIFT kernels' workgroups per CU
+    int fwd_dbg = 0;              // ablations: 1 = skip output stores, 2 = all taps out of range, 256 = free first item
+    int prologue_blocks_per_cu = 3;
+    int prologue_aux = 0;         // store policy of the prologue's relayout: 0 plain (ships), 16 write-through
+    // store policy of the backward's top_diff relayout (tools/bwd_profile.py with RROI_BWD_SWEEP=1, four runs):
+    // write-through (sc1) 163.4-165.9 us per call, streaming (nt) 166.8-168.8, plain 166.2-169.2 -- write-through
+    // leaves no dirty lines for the end of the launch to flush.  Non-temporal LOADS in the gather: +16 us.
+    int bwd_relayout_aux = 16;
+    int bwd_buckets = 1;          // one-pass pixel lists (round 3); 0: count / scan / fill as in rounds 1-2
+};
+#ifdef RROI_EXPLORE
+Tuning g_tune;
+#else
+constexpr Tuning g_tune{};
+#endif
+
 // Row pitch (pixels = 128-byte lines) of the chunk-major copy: W plus a pad that makes the
 // pitch odd, so that the lines of vertically adjacent pixels differ in their low address
 // bits and spread over the L2 channels.
-int g_row_pad = -1;  // exploration knob: -1 = automatic
 int row_pitch(int width)
 {
-    if (g_row_pad >= 0) return width + g_row_pad;
+    if (g_tune.row_pad >= 0) return width + g_tune.row_pad;
     return width | 1;
 }
 
@@ -103,26 +131,14 @@ bool shape_ok(int batch_size, int num_rois, int height, int width, int channels,
     return true;
 }
 
-// grid for the tiled kernels: one wave per block, 12 waves per CU -- what the forward
-// kernel's 12.4 KB of LDS admits (LDS is granted in 1280-byte granules; a grid larger than
-// the resident set would run its surplus blocks as a second, mostly empty round) -- and a
-// multiple of lcm(nchunks, 8) so that blockIdx % nchunks is also stable per XCD.
-int g_waves_per_cu = 12;
-
-// the split forward kernel: workgroups of a gatherer and a storer wave; 62-64 VGPRs under __launch_bounds__(128, 6)
-// and 12.1 KB of LDS (10 granules of 1280 B) -> 12 workgroups per CU; a larger grid would run its surplus as a second
-// round.  (Round 3's first form, <EARLY = 2, OCC = 5, HID = 2>: 90 VGPRs, 10 per CU.)
-int g_split_wgs_per_cu = 12;
-int g_shift_pre = 1;        // SHIFT: runs that start inside a block begin with a pre item (no partial sectors at cuts)
-int g_shift_parts = 0;      // exploration: > 0 forces the runs per (roi, chunk) block
-int g_shift_wgs_per_cu = 0;   // exploration: > 0 overrides the SHIFT kernels' workgroups per CU
-int g_fwd_shift = 1;  // 1: crops with PH * PW % 16 != 0 take the split kernel's SHIFT form
-int g_fwd_split = 1;  // 1: loads and stores in different waves (rroi_fwd_split_kernel) for NCHW crops
-
+// grid for the tiled kernels: `per_cu` workgroups per CU (default: the one-wave kernels' 12 -- what their 12.4 KB of
+// LDS admits; LDS is granted in 1280-byte granules, and a grid larger than the resident set would run its surplus
+// blocks as a second, mostly empty round) and a multiple of lcm(nchunks, 8) so that blockIdx % nchunks is also
+// stable per XCD.
 int tiled_grid(long items, int nchunks, int per_cu = 0)
 {
     long want = items * nchunks;
-    const long cap = (long)num_cus() * (per_cu > 0 ? per_cu : g_waves_per_cu);
+    const long cap = (long)num_cus() * (per_cu > 0 ? per_cu : g_tune.waves_per_cu);
     if (want > cap) want = cap;
     long unit = nchunks;
     while (unit % 8) unit += nchunks;  // lcm(nchunks, 8)
@@ -300,21 +316,66 @@ bool pick_tiled_bwd(int batch_size, int channels, int height, int width, int num
     return out_elems >= 0.2e6 || map_elems >= 8.0e6;
 }
 
-int g_store_aux = 2;   // cache policy of the output stores (see buf_store); 16 / 0 for exploration
-int g_fwd_dbg = 0;     // ablation: 1 = skip output stores, 2 = all taps out of range
-#ifdef RROI_EXPLORE
-int g_fwd_minor = 1;   // exploration: write-through stores per tile (template parameter MINOR)
-int g_fwd_early = 2;   // exploration: LO groups issued ahead of the stores (template parameter EARLY)
-#endif
-int g_prologue_blocks_per_cu = 3;
-int g_prologue_aux = 0;
-// store policy of the backward's top_diff relayout (tools/bwd_profile.py with RROI_BWD_SWEEP=1, four
-// runs): write-through (sc1) 163.4-165.9 us per call, streaming (nt) 166.8-168.8, plain 166.2-169.2 --
-// write-through leaves no dirty lines for the end of the launch to flush.  (Round 1, with two more
-// launches in the call, had nt ahead by 2 us.)  Non-temporal LOADS in the gather: +16 us.
-int g_bwd_relayout_aux = 16;
-int g_bwd_buckets = 1;  // one-pass pixel lists (round 3); 0: count / scan / fill as in rounds 1-2
 
+// ------------------------------------------------------------------------------------
+// Which instantiation of rroi_fwd_split_kernel gathers a problem, with what grid and flags.
+// ------------------------------------------------------------------------------------
+enum class FwdKernel {
+    kStrided,        // every n-th (roi, tile) item per workgroup, 16-byte stores: crops whose rows are whole sectors
+    kStridedScalar,  // the same with dword stores (PH * PW % 4 != 0) -- small problems only, see shift_pays
+    kChannelsLast,   // channels-last crops (R, PH, PW, C)
+    kShift16,        // SHIFT = 1: runs of tiles, every row a multiple of 16 bytes into its sector
+    kShiftAny,       // SHIFT = 2: runs of tiles, any row offset (also crops that start 4 bytes off)
+};
+struct ForwardPlan {
+    FwdKernel kernel;
+    int grid;
+    int dbg;   // the kernel's flag word (see its header comment)
+};
+
+ForwardPlan plan_forward_gather(int num_rois, int channels, int NB, int ntiles, int nchunks, bool out_nhwc,
+                                bool launcher_rest, bool out_aligned16)
+{
+    const long items = (long)num_rois * ntiles;
+    const int base_dbg = (g_tune.fwd_dbg & ~0xe0) | (launcher_rest ? 32 : 0);   // bits 5-7 are the host's
+    if (out_nhwc)   // (91 VGPRs -> five waves per SIMD: 10 workgroups per CU are resident, and no more are launched)
+        return {FwdKernel::kChannelsLast, tiled_grid(items, nchunks, 10), g_tune.fwd_dbg & ~0xe0};
+    // Crops whose rows are not whole 64-byte sectors (PH * PW % 16 != 0) take the SHIFT forms: a (roi, chunk) block of
+    // ntiles tiles is cut into `parts` runs for the workgroups of its chunk.  Every cut costs two partial sectors per
+    // channel row, every run shorter than the block buys parallelism: measured (tools/align_probe.py, 11 x 100 and
+    // 11 x 83 crops, R = 8 ... 2048, C = 64 / 256) the best cut is about one run per workgroup while the ROIs are fewer
+    // than the workgroups of a chunk -- 2 for R = 512 on 1280 slots (39 us; 1: 49, 3: 46, 9: 51), 6 for R = 128 on 1024
+    // (18; 2: 32, 15: 24) -- and none beyond.  With PRE items (SHIFT = 1 only: a run that starts inside a block samples
+    // the last 16 columns of the tile before it first, stores nothing of them, and so starts on a whole sector; the run
+    // before it has nothing to flush) a cut costs a quarter of a tile's work instead of partial sectors, and six runs
+    // per block are as good as or better than the best cut without them everywhere measured (R = 2048, C = 64,
+    // 11 x 100: 124.5 against 135.5 us; R = 512: 35.7 against 38.0; profiles/r03_align_parts.txt).  The SHIFT = 2 storer
+    // is the heavier wave already: there they cost more than they save (R = 512, 11 x 83: 51 against 42 us).
+    auto shift_parts = [&](int wgs_per_cu, bool pre) {
+        if (g_tune.shift_parts > 0) return std::min(g_tune.shift_parts, ntiles);
+        const long per_roi = std::max(1L, (long)num_cus() * wgs_per_cu / nchunks) / std::max(1, num_rois);
+        long m = pre ? std::max(6L, 3 * per_roi / 4) : per_roi <= 3 ? per_roi : 3 * per_roi / 4;
+        m = std::max(1L, std::min<long>(m, ntiles));
+        while (m > 1 && (m - 1) * ceil_div(ntiles, (int)m) >= ntiles) --m;   // no empty last part
+        return (int)m;
+    };
+    // small problems stay with the strided items (latency-bound: 12 workgroups per CU all busy beats whole sectors) --
+    // from 5 workgroups of a chunk per roi up when the rows are multiples of 16 bytes (R = 128, C = 64, 11 x 100: 15.3
+    // against 15.1 us; R = 32: 6.3 against 8.2), from 32 up otherwise, where the strided form stores dwords (R = 32,
+    // C = 64, 11 x 83: 10.0 against 9.2; R = 8: 5.1 against 7.3; R = 128: 51 against 18)
+    const long slots_per_roi = std::max(1L, (long)num_cus() * g_tune.split_wgs_per_cu / nchunks) / std::max(1, num_rois);
+    const bool shift_pays = g_tune.fwd_shift == 2 || slots_per_roi < (NB % 4 == 0 ? 5 : 32);
+    if (g_tune.fwd_shift && (NB % 16 != 0 || g_tune.fwd_shift == 2) && shift_pays) {
+        const bool s16 = NB % 4 == 0 && out_aligned16;   // every row starts a multiple of 16 bytes into its sector
+        const int wpc = g_tune.shift_wgs_per_cu > 0 ? g_tune.shift_wgs_per_cu : s16 ? 10 : 8;
+        const bool pre = g_tune.shift_pre && s16;
+        const int sp = shift_parts(wpc, pre);
+        return {s16 ? FwdKernel::kShift16 : FwdKernel::kShiftAny, tiled_grid((long)num_rois * sp, nchunks, wpc),
+                (base_dbg & 63) | (sp > 1 && pre ? 64 : 0) | (sp << 8)};   // (bits 8.. = the runs per block)
+    }
+    return {NB % 4 == 0 ? FwdKernel::kStrided : FwdKernel::kStridedScalar, tiled_grid(items, nchunks, g_tune.split_wgs_per_cu),
+            base_dbg};
+}
 
 // ------------------------------------------------------------------------------------
 // Scratch of the reference-ABI launchers.  Their signatures carry no workspace, so the library keeps
@@ -550,8 +611,8 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         const int relayout_tiles = zero_copy ? 0 : ptiles * nchunks * batch_size;
         // ~3 resident blocks per CU, each streaming several tiles with the next tile prefetched
         int relayout_blocks = relayout_tiles;
-        if (relayout_blocks > num_cus() * g_prologue_blocks_per_cu) {
-            relayout_blocks = num_cus() * g_prologue_blocks_per_cu;
+        if (relayout_blocks > num_cus() * g_tune.prologue_blocks_per_cu) {
+            relayout_blocks = num_cus() * g_tune.prologue_blocks_per_cu;
             long unit = nchunks;
             while (unit % 8) unit += nchunks;  // lcm(nchunks, 8): keeps block -> chunk -> XCD stable
             if (relayout_blocks >= unit) relayout_blocks = (int)(relayout_blocks / unit * unit);
@@ -566,8 +627,11 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
                        relayout_tiles, batch_size, rois, num_rois, pooled_height,                     \
                        spatial_scale, ws.aff, aff_blocks, launcher_rest ? top_data : (float*)nullptr, \
                        pooled_width)
-        if (g_prologue_aux == 16) RROI_LAUNCH_PRO(16);
-        else RROI_LAUNCH_PRO(0);
+#ifdef RROI_EXPLORE
+        if (g_tune.prologue_aux == 16) RROI_LAUNCH_PRO(16);
+        else
+#endif
+        RROI_LAUNCH_PRO(0);
 #undef RROI_LAUNCH_PRO
         const int st = launch_status();
         if (st != 1) return st;
@@ -575,7 +639,6 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     if (stages & RROI_STAGE_GATHER) {
         const int ntiles = ceil_div(NB, kTileBins);
         if ((long)num_rois * ntiles >= (1L << 31)) return 0;
-        const int grid = tiled_grid((long)num_rois * ntiles, nchunks);
         SliceLayout lay;
         if (zero_copy) {
             lay.px_bytes = (unsigned)channels * 4u;
@@ -591,204 +654,30 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
             lay.img_stride = lay.chunk_stride * (unsigned)nchunks;
         }
         const FastDiv dt = make_fastdiv((unsigned)ntiles), dp = make_fastdiv((unsigned)pooled_width);
-#define RROI_LAUNCH_FWD(VEC, AUX)                                                                    \
-    hipLaunchKernelGGL((rroi_fwd_tiled_kernel<VEC, AUX>), dim3(grid), dim3(kWave), 0, stream, map,   \
-                       ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,        \
-                       batch_size, nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
-        const int sgrid = tiled_grid((long)num_rois * ntiles, nchunks, g_split_wgs_per_cu);
-        // SHIFT kernels: a (roi, chunk) block of ntiles tiles is cut into `parts` runs for the workgroups of its chunk.
-        // Every cut costs two partial sectors per channel row, every run shorter than the block buys parallelism:
-        // measured (tools/align_probe.py, 11 x 100 and 11 x 83 crops, R = 8 ... 2048, C = 64 / 256) the best cut is
-        // about one run per workgroup while the ROIs are fewer than the workgroups of a chunk -- 2 for R = 512 on
-        // 1280 slots (39 us; 1: 49, 3: 46, 9: 51), 6 for R = 128 on 1024 (18; 2: 32, 15: 24) -- and none beyond.
-        // With PRE items (SHIFT = 1 only: a run that starts inside a block samples the last 16 columns of the tile
-        // before it first, stores nothing of them, and so starts on a whole sector; the run before it has nothing to
-        // flush) a cut costs a quarter of a tile's work instead of partial sectors, and six runs per block are as good
-        // as or better than the best cut without them everywhere measured (R = 2048, C = 64, 11 x 100: 124.5 against
-        // 135.5 us; R = 512: 35.7 against 38.0; profiles/r03_align_parts.txt).  The SHIFT = 2 storer is the heavier
-        // wave already: there they cost more than they save (R = 512, 11 x 83: 51 against 42 us).
-        auto shift_parts = [&](int wgs_per_cu, bool pre) {
-            if (g_shift_parts > 0) return std::min(g_shift_parts, ntiles);
-            const long per_roi = std::max(1L, (long)num_cus() * wgs_per_cu / nchunks) / std::max(1, num_rois);
-            long m = pre ? std::max(6L, 3 * per_roi / 4) : per_roi <= 3 ? per_roi : 3 * per_roi / 4;
-            m = std::max(1L, std::min<long>(m, ntiles));
-            while (m > 1 && (m - 1) * ceil_div(ntiles, (int)m) >= ntiles) --m;   // no empty last part
-            return (int)m;
-        };
-        // small problems stay with the strided items (latency-bound: 12 workgroups per CU all busy beats whole
-        // sectors) -- from 5 workgroups of a chunk per roi up when the rows are multiples of 16 bytes (R = 128, C = 64,
-        // 11 x 100: 15.3 against 15.1 us; R = 32: 6.3 against 8.2), from 32 up otherwise, where the strided form
-        // stores dwords (R = 32, C = 64, 11 x 83: 10.0 against 9.2; R = 8: 5.1 against 7.3; R = 128: 51 against 18)
-        const long split_slots_per_roi = std::max(1L, (long)num_cus() * g_split_wgs_per_cu / nchunks) / std::max(1, num_rois);
-        const bool shift_pays = g_fwd_shift == 2 || split_slots_per_roi < (NB % 4 == 0 ? 5 : 32);
-        // EARLY = 0, six waves per SIMD, double-buffered HI groups, 12 workgroups per CU (tools/split_explore.py, three
-        // to four interleaved rounds): as fast as <2, 1, 5, 2> with 10 per CU on the default draw (step 53.5-53.75
-        // against 53.45-53.85 us, gather alone 44.5-44.9 against 45.5-46.1) and faster where the gatherer waves are the
-        // critical path -- every bin active (w = 8 h): step 55.4-55.9 against 57.0-57.3 us
-#define RROI_LAUNCH_SPLIT(VEC)                                                                           \
-    hipLaunchKernelGGL((rroi_fwd_split_kernel<VEC, 2, 0, 1, 6, 3>), dim3(sgrid), dim3(2 * kWave), 0, stream, map, \
-                       ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size, \
-                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg | (launcher_rest ? 32 : 0))
-        // channels-last crops: the split kernel behind the prologue (55.2 against 56.4-58.6 us at cfg2); with
-        // channels-last features consumed in place the one-wave kernel is as fast or faster (51.6 against 52.3)
-        if (out_nhwc && !zero_copy && g_fwd_split && g_store_aux == 2)
-            // (five waves per SIMD: 10 workgroups per CU are resident, and no more are launched)
-            hipLaunchKernelGGL((rroi_fwd_split_kernel<true, 2, 2, 1, 5, 2, true>),
-                               dim3(tiled_grid((long)num_rois * ntiles, nchunks, 10)), dim3(2 * kWave), 0, stream,
-                               map, ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,
-                               nchunks, ntiles, lay, dt, dp, g_fwd_dbg);
-        else if (out_nhwc)
-            hipLaunchKernelGGL((rroi_fwd_tiled_kernel<true, 2, true>), dim3(grid), dim3(kWave), 0, stream, map,
-                               ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB,
-                               batch_size, nchunks, ntiles, lay, dt, dp, g_fwd_dbg);
-#ifdef RROI_EXPLORE
-#define RROI_LAUNCH_SPLIT_X(E, O, H)                                                                         \
-    hipLaunchKernelGGL((rroi_fwd_split_kernel<true, 2, E, 1, O, H>), dim3(sgrid), dim3(2 * kWave), 0, stream, \
-                       map, ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size, \
-                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
-        else if (g_fwd_split == 2) RROI_LAUNCH_SPLIT_X(2, 5, 2);   // round 3's first shipped form (with 10 per CU)
-        else if (g_fwd_split == 3) RROI_LAUNCH_SPLIT_X(1, 6, 3);
-        else if (g_fwd_split == 4) RROI_LAUNCH_SPLIT_X(2, 6, 3);
-        else if (g_fwd_split == 5) RROI_LAUNCH_SPLIT_X(2, 5, 3);
-        else if (g_fwd_split == 6) RROI_LAUNCH_SPLIT_X(0, 6, 1);
-#undef RROI_LAUNCH_SPLIT_X
-#endif
-        // crops whose rows are not whole 64-byte sectors: runs of tiles per workgroup, sector-aligned store windows
-        // (rroi_fwd_split_kernel<..., SHIFT>); 14.2 KB of LDS -> 10 workgroups per CU
-#define RROI_LAUNCH_SHIFT(S, O, W)                                                                            \
-    do {                                                                                                      \
-        const int wpc = g_shift_wgs_per_cu > 0 ? g_shift_wgs_per_cu : W;                                      \
-        const bool pre = g_shift_pre && S == 1;                                                               \
-        const int sp = shift_parts(wpc, pre);                                                                 \
-        hipLaunchKernelGGL((rroi_fwd_split_kernel<true, 2, 0, 1, O, 3, false, S>),                            \
-                           dim3(tiled_grid((long)num_rois * sp, nchunks, wpc)), dim3(2 * kWave), 0, stream, map, \
-                           ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,   \
-                           nchunks, ntiles, lay, dt, dp,                                                        \
-                           (g_fwd_dbg & 31) | (launcher_rest ? 32 : 0) | (sp > 1 && pre ? 64 : 0) | (sp << 8)); \
-    } while (0)
-        else if ((g_fwd_split || launcher_rest) && g_store_aux == 2 && (NB % 16 != 0 || g_fwd_shift == 2) && g_fwd_shift && shift_pays) {
-            // 1: every row starts a multiple of 16 bytes into its sector; 2: any offset
-            if (NB % 4 == 0 && reinterpret_cast<size_t>(top_data) % 16 == 0) RROI_LAUNCH_SHIFT(1, 5, 10);   // 96 VGPRs, 14.2 KB of LDS: 10 workgroups per CU
-            else RROI_LAUNCH_SHIFT(2, 4, 8);                                    // 120 VGPRs: 8 per CU
+        const ForwardPlan plan = plan_forward_gather(num_rois, channels, NB, ntiles, nchunks, out_nhwc, launcher_rest,
+                                                     reinterpret_cast<size_t>(top_data) % 16 == 0);
+        // the shipped instantiations of rroi_fwd_split_kernel<VEC_STORE, EARLY, OCC, HID, ONHWC, SHIFT>, one per FwdKernel
+#define RROI_GATHER(...)                                                                                              \
+    hipLaunchKernelGGL((rroi_fwd_split_kernel<__VA_ARGS__>), dim3(plan.grid), dim3(2 * kWave), 0, stream, map, ws.aff, \
+                       top_data, num_rois, channels, height, width, pooled_width, NB, batch_size, nchunks, ntiles, lay, \
+                       dt, dp, plan.dbg)
+        switch (plan.kernel) {
+        case FwdKernel::kStrided:       RROI_GATHER(true, 0, 6, 3, false, 0); break;   // 62-64 VGPRs, 12.1 KB of LDS: 12 per CU
+        case FwdKernel::kStridedScalar: RROI_GATHER(false, 0, 6, 3, false, 0); break;
+        case FwdKernel::kChannelsLast:  RROI_GATHER(true, 2, 5, 2, true, 0); break;    // 91 VGPRs: 10 per CU
+        case FwdKernel::kShift16:       RROI_GATHER(true, 0, 5, 3, false, 1); break;   // 96 VGPRs, 14.2 KB of LDS: 10 per CU
+        case FwdKernel::kShiftAny:      RROI_GATHER(true, 0, 4, 3, false, 2); break;   // 117 VGPRs: 8 per CU
         }
-#undef RROI_LAUNCH_SHIFT
-        else if ((g_fwd_split || launcher_rest) && g_store_aux == 2 && NB % 4 != 0) RROI_LAUNCH_SPLIT(false);
-        else if ((g_fwd_split || launcher_rest) && g_store_aux == 2) RROI_LAUNCH_SPLIT(true);
-        else if (NB % 4 != 0) RROI_LAUNCH_FWD(false, 2);
-        else if (g_store_aux == 0) RROI_LAUNCH_FWD(true, 0);    // exploration only
-        else if (g_store_aux == 16) RROI_LAUNCH_FWD(true, 16);  // exploration only
-        else if (g_store_aux == 3) RROI_LAUNCH_FWD(true, 3);    // exploration only: pure nt (sc0 nt)
-#ifdef RROI_EXPLORE
-#define RROI_LAUNCH_FWD_E(E)                                                                              \
-    hipLaunchKernelGGL((rroi_fwd_tiled_kernel<true, 2, false, E>), dim3(grid), dim3(kWave), 0, stream, map, \
-                       ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,     \
-                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
-#define RROI_LAUNCH_FWD_M(M)                                                                              \
-    hipLaunchKernelGGL((rroi_fwd_tiled_kernel<true, 2, false, 2, M>), dim3(grid), dim3(kWave), 0, stream, map, \
-                       ws.aff, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,     \
-                       nchunks, ntiles, lay, dt, dp, g_fwd_dbg)
-        else if (g_fwd_minor == 2) RROI_LAUNCH_FWD_M(2);
-        else if (g_fwd_minor == 3) RROI_LAUNCH_FWD_M(3);
-        else if (g_fwd_minor == 4) RROI_LAUNCH_FWD_M(4);
-#undef RROI_LAUNCH_FWD_M
-        else if (g_fwd_early == 1) RROI_LAUNCH_FWD_E(1);
-        else if (g_fwd_early == 3) RROI_LAUNCH_FWD_E(3);
-        else if (g_fwd_early == 4) RROI_LAUNCH_FWD_E(4);
-        else if (g_fwd_early == 5) RROI_LAUNCH_FWD_E(5);
-#undef RROI_LAUNCH_FWD_E
-#endif
-        else RROI_LAUNCH_FWD(true, 2);
-#undef RROI_LAUNCH_FWD
-#undef RROI_LAUNCH_SPLIT
+#undef RROI_GATHER
     }
     return launch_status();
 }
 
-// Exploration knobs for the sweeps and ablations quoted in DESIGN.md: compiled only with
-// -DRROI_EXPLORE (tools/kbench.hip, `make EXPLORE=1`).  The product library does not export them;
-// the defaults above are the shipped configuration.
+// Exploration knobs for the sweeps and ablations quoted in the notebook: tools/rroi_explore_setters.h, compiled only
+// with -DRROI_EXPLORE (tools/kbench.hip, tools/build_explore.sh).  The product library does not export them.
 #ifdef RROI_EXPLORE
-int rroi_align_debug_set_store_aux(int v)
-{
-    const int old = g_store_aux;
-    g_store_aux = v;
-    return old;
-}
-int rroi_align_debug_set_bwd_relayout_aux(int v)
-{
-    const int old = g_bwd_relayout_aux;
-    g_bwd_relayout_aux = v;
-    return old;
-}
-int rroi_align_debug_set_fwd_split(int on, int wgs_per_cu)
-{
-    const int old = g_fwd_split;
-    if (on >= 0) g_fwd_split = on;
-    if (wgs_per_cu > 0) g_split_wgs_per_cu = wgs_per_cu;
-    return old;
-}
-int rroi_align_debug_set_fwd_shift(int v, int wgs_per_cu, int parts)
-{
-    const int old = g_fwd_shift;
-    if (v >= 0) g_fwd_shift = v;
-    if (wgs_per_cu >= 0) g_shift_wgs_per_cu = wgs_per_cu;
-    if (parts >= 0) g_shift_parts = parts & 255;
-    if (parts >= 0) g_shift_pre = (parts & 256) ? 0 : 1;   // + 256: without the pre items
-    return old;
-}
-int rroi_align_debug_set_wg_trace(unsigned* device_buffer)
-{
-    return status_of(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace), &device_buffer, sizeof(device_buffer)));
-}
-int rroi_align_debug_set_bwd_buckets(int v)
-{
-    const int old = g_bwd_buckets;
-    g_bwd_buckets = v;
-    return old;
-}
-int rroi_align_debug_set_fwd_dbg(int v)
-{
-    const int old = g_fwd_dbg;
-    g_fwd_dbg = v;
-    return old;
-}
-int rroi_align_debug_set_fwd_minor(int v)
-{
-    const int old = g_fwd_minor;
-    g_fwd_minor = v;
-    return old;
-}
-int rroi_align_debug_set_fwd_early(int v)
-{
-    const int old = g_fwd_early;
-    g_fwd_early = v;
-    return old;
-}
-int rroi_align_debug_set_prologue_blocks(int v)
-{
-    const int old = g_prologue_blocks_per_cu;
-    if (v >= 1 && v <= 64) g_prologue_blocks_per_cu = v;
-    return old;
-}
-int rroi_align_debug_set_prologue_aux(int v)
-{
-    const int old = g_prologue_aux;
-    g_prologue_aux = v;
-    return old;
-}
-int rroi_align_debug_set_row_pad(int v)
-{
-    const int old = g_row_pad;
-    g_row_pad = v;
-    return old;
-}
-int rroi_align_debug_set_waves_per_cu(int v)
-{
-    const int old = g_waves_per_cu;
-    if (v >= 1 && v <= 64) g_waves_per_cu = v;
-    return old;
-}
-#endif  // RROI_EXPLORE
+#include "../../tools/rroi_explore_setters.h"
+#endif
 
 int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batch_size,
                             int num_rois, int height, int width, int channels,
@@ -904,7 +793,7 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
     // 200 / 128 / 318): the bucket grows with the density as far as carve_bwd's cap lets it, bucket_pref says if
     // that was far enough.
     const bool buckets = gather && ws.bucket_ok && gather_choice_is_open(path) &&
-                         (path == RROI_PATH_TILED_BUCKETS || (ws.bucket_pref && g_bwd_buckets));
+                         (path == RROI_PATH_TILED_BUCKETS || (ws.bucket_pref && g_tune.bwd_buckets));
     const bool lists = buckets || path == RROI_PATH_TILED_LISTS || !inkernel_ok ||
                        (path != RROI_PATH_TILED_INKERNEL && !prefer_inkernel);
     const BucketLists BL = {ws.kshift, reinterpret_cast<int*>(ws.off), ws.bsum, ws.ov};
@@ -944,9 +833,12 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
                        stream, ws.aff, num_rois, height, width, pooled_width, NB, batch_size, lines_per_roi, \
                        dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs, 0, top_diff, ws.tdT, channels,       \
                        nchunks, tt, (int)blocks, 0, (int)tiles, ws.scan_blocks, 0)
-            if (g_bwd_relayout_aux == 16) RROI_LAUNCH_R(16);
-            else if (g_bwd_relayout_aux == 2) RROI_LAUNCH_R(2);
-            else RROI_LAUNCH_R(0);
+#ifdef RROI_EXPLORE
+            if (g_tune.bwd_relayout_aux == 2) RROI_LAUNCH_R(2);
+            else if (g_tune.bwd_relayout_aux == 0) RROI_LAUNCH_R(0);
+            else
+#endif
+            RROI_LAUNCH_R(16);
 #undef RROI_LAUNCH_R
             st = launch_status();
             if (st != 1) return st;
@@ -1016,24 +908,33 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
         if (buckets) {
             // ONE launch: every pair into its pixel's bucket (or overflow chain) || the whole relayout
             const long blocks = relayout_grid(tiles);
-            if (g_bwd_relayout_aux == 16) RROI_LAUNCH_PR(2, 16, blocks, 0, tiles);
-            else if (g_bwd_relayout_aux == 2) RROI_LAUNCH_PR(2, 2, blocks, 0, tiles);
-            else RROI_LAUNCH_PR(2, 0, blocks, 0, tiles);
+#ifdef RROI_EXPLORE
+            if (g_tune.bwd_relayout_aux == 2) RROI_LAUNCH_PR(2, 2, blocks, 0, tiles);
+            else if (g_tune.bwd_relayout_aux == 0) RROI_LAUNCH_PR(2, 0, blocks, 0, tiles);
+            else
+#endif
+            RROI_LAUNCH_PR(2, 16, blocks, 0, tiles);
         } else {
         {
             const long blocks = relayout_grid(half);
-            if (g_bwd_relayout_aux == 16) RROI_LAUNCH_PR(0, 16, blocks, 0, half);
-            else if (g_bwd_relayout_aux == 2) RROI_LAUNCH_PR(0, 2, blocks, 0, half);
-            else RROI_LAUNCH_PR(0, 0, blocks, 0, half);
+#ifdef RROI_EXPLORE
+            if (g_tune.bwd_relayout_aux == 2) RROI_LAUNCH_PR(0, 2, blocks, 0, half);
+            else if (g_tune.bwd_relayout_aux == 0) RROI_LAUNCH_PR(0, 0, blocks, 0, half);
+            else
+#endif
+            RROI_LAUNCH_PR(0, 16, blocks, 0, half);
         }
         hipLaunchKernelGGL(rroi_scan1_kernel, dim3(ws.scan_blocks), dim3(1024), 0, stream, ws.cnt, ws.off,
                            ws.bsum, KL.keys);
         if (!raw_bsum) hipLaunchKernelGGL(rroi_scan2_kernel, dim3(1), dim3(1024), 0, stream, ws.bsum, ws.scan_blocks);
         {
             const long blocks = relayout_grid(tiles - half);
-            if (g_bwd_relayout_aux == 16) RROI_LAUNCH_PR(1, 16, blocks, half, tiles);
-            else if (g_bwd_relayout_aux == 2) RROI_LAUNCH_PR(1, 2, blocks, half, tiles);
-            else RROI_LAUNCH_PR(1, 0, blocks, half, tiles);
+#ifdef RROI_EXPLORE
+            if (g_tune.bwd_relayout_aux == 2) RROI_LAUNCH_PR(1, 2, blocks, half, tiles);
+            else if (g_tune.bwd_relayout_aux == 0) RROI_LAUNCH_PR(1, 0, blocks, half, tiles);
+            else
+#endif
+            RROI_LAUNCH_PR(1, 16, blocks, half, tiles);
         }
         }
 #undef RROI_LAUNCH_PR

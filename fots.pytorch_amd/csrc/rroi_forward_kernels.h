@@ -245,402 +245,28 @@ __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois,
 }
 
 // ------------------------------------------------------------------------------------
-// K1: the hot kernel.  One wave per block; block -> channel chunk k = blockIdx %
-// nchunks (XCD affinity) and a grid-stride loop over (roi, 64-bin tile) items.
-//   phase A  lane = bin: geometry -> one 16-byte tap record per bin in LDS, sorted by
-//            class (bins with <= 2 distinct taps, bins with 4); an invalid tap is the
-//            out-of-range offset kOOB, which the buffer descriptor turns into 0.0.
-//   phase B  lane = (bin b of 8, channel quad q of 8): 2 or 4 buffer loads per group
-//            of 8 bins, blend, transpose through LDS; depth-2 software pipeline.
-//   phase C  the [32 ch][64 bin] tile leaves LDS as 16-byte streaming stores, 256 B
-//            per row.
-// The three phases of consecutive items are interleaved around the store burst, see the
-// loop at the end.
+// K1: the hot kernel, rroi_fwd_split_kernel.  A workgroup is two waves on one LDS tile; block -> channel chunk
+// k = blockIdx % nchunks (XCD affinity) and a walk over (roi, 64-bin tile) items:
+//   phase A  (storer wave) lane = bin: geometry -> one 16-byte tap record per bin in LDS, sorted by class (bins
+//            with <= 2 distinct taps, bins with 4); an invalid tap is the out-of-range offset kOOB, which the
+//            buffer descriptor turns into 0.0.  No memory access: it fills the time the storer would idle.
+//   phase B  (gatherer wave) lane = (bin b of 8, channel quad q of 8): 2 or 4 buffer loads per group of 8 bins,
+//            blend, transpose through the LDS tile; the loads of group g + 1 are in flight while group g is blended.
+//   phase C  (storer wave) the [32 ch][64 bin] tile leaves LDS as 16-byte stores, 256 B per row (or, ONHWC, 8 bins x
+//            128 B of channels-last crops), seven of eight streaming, one write-through.
+// gfx950 counts loads and stores with ONE in-order vmcnt: a wave that does both cannot consume a load issued behind
+// its stores before those stores are acknowledged (microseconds while 256 MiB stream out).  Rounds 1-2 ordered the
+// phases of a one-wave kernel around that (rroi_fwd_tiled_kernel: retired in round 4, see profiles/NOTEBOOK.md);
+// here no wave does both.
+// Template parameters: VEC_STORE 16-byte stores (PH * PW % 4 == 0) | EARLY LO groups issued before barrier 2 | OCC
+// waves per SIMD (__launch_bounds__) | HID HI groups double-buffered unrolled (2) or rolled (3) | ONHWC channels-last
+// crops | SHIFT crops whose rows are not whole 64-byte sectors: runs of tiles and sector-aligned store windows (1:
+// every row a multiple of 16 bytes into its sector, 2: any offset; see drain_shift).  dbg: bit 0 drops the stores, bit 1
+// the tap loads (ablations), bit 5 the reference-ABI launcher's mode, bit 6 SHIFT's pre items, bits 8.. SHIFT's runs
+// per (roi, chunk) block.  Shipped instantiations: the switch in forward_impl (rroi_align_hip.hip).
 // ------------------------------------------------------------------------------------
-template <bool VEC_STORE, int AUX, bool ONHWC = false, int EARLY = 2, int MINOR = 1>
-__global__ __launch_bounds__(kWave) void rroi_fwd_tiled_kernel(
-    const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
-    int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
-    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg)
-{
-    // A tile's bins are processed in CLASS-SORTED groups of 8, because the texture addresser
-    // charges 16 cycles for every dwordx4 wave instruction whatever the number of lanes that
-    // really fetch (measured: 16.1 / 15.6 / 15.2 clk with 0 / 50 / 87 % of the lanes out of
-    // range).  Issuing all 4 taps for all 64 bins costs 32 load instructions per tile although
-    // only ~1.3 taps per bin are distinct pixels.  Sorted:
-    //   LO  bins with at most two distinct taps (lt, and rt OR lb): 2 loads per group;
-    //   HI  bins with four distinct taps (dx and dy):                4 loads per group;
-    //   masked bins (pw > roi_pooled_width) are in no group -- phase C writes their zeros.
-    // Typical tile: 5 LO + 2 HI groups = 18 load instructions instead of 32.
-    // two classes, each padded to a multiple of 8: ceil(a/8) + ceil(b/8) <= 9 for a + b <= 64 (and one
-    // forced LO group + 8 HI groups when a = 0)
-    constexpr int kMaxGroups = kIters + 1;
-    // LO groups whose loads are issued ahead of the previous tile's stores.  A/B in one process (tools/kbench
-    // early, three rounds): 1 group 46.1-47.2 us kernel / 53.85 us step, 2 groups 45.45 / 53.45, 3 45.7 / 53.65,
-    // 4 46.4 / 53.9, 5 47.3 / 54.75
-    constexpr int kEarly = EARLY;
-    constexpr unsigned kPadPos = kTileBins;  // "bin position" of a padding record
-    // T: rows 0..31 are the tile; the tail absorbs the writes of padding records (4 rows at the
-    // tile's pitch, 32 columns: 32 different banks).  LDS is granted in 1280-byte granules on gfx950;
-    // the block (T 9648 + records 2448 = 12096 B) stays within the 10 granules that 12 waves per CU
-    // allow.  Round 2 also tried a block of 11152 B (padding writes into the four spare columns of the
-    // tile pitch), which admits 14 waves per CU: 12 waves 47.2 us, 13 48.0, 14 48.5 (tools/kbench abl)
-    // -- the kernel is bound by the write path, not by latency -- and the spare-column writes are
-    // 4-way bank-conflicted (SQ_LDS_BANK_CONFLICT 40 % instead of 32 % of the LDS cycles): not kept.
-    __shared__ __attribute__((aligned(16))) float T[kChunk * kTStride + 3 * kTStride + 32];
-    // tap records of two items: item i+1 is sampled out of one set while the other is being
-    // built for item i+2
-    constexpr int kRecs = kMaxGroups * kBinsPerIter;
-    __shared__ __attribute__((aligned(16))) uint4 Gbuf[2 * kRecs];
-    __shared__ unsigned char HPbuf[2 * kRecs];
-
-    const unsigned lane = threadIdx.x;
-    const unsigned k = blockIdx.x % (unsigned)nchunks;
-    const unsigned slot = blockIdx.x / (unsigned)nchunks;
-    const unsigned nslots = gridDim.x / (unsigned)nchunks;
-    const unsigned items = (unsigned)num_rois * (unsigned)ntiles;
-    const unsigned px_bytes = lay.px_bytes;
-    const unsigned row_bytes = lay.row_bytes;
-
-    // lane = q + 8*b: the 8 lanes that fetch the 8 channel quads of ONE pixel (one 128-byte
-    // line) are consecutive, so the texture addresser merges them into two 64-byte
-    // accesses.  (With the quads strided over the wave every lane costs its own access:
-    // measured 43 vs 16 TCP accesses per load instruction.)
-    const unsigned q = lane & (kQuads - 1), b = lane >> 3;
-    // a channel quad wholly beyond C never loads (its rows are not stored either)
-    const unsigned q_bytes = ((dbg & 2) || k * kChunk + q * 4 >= (unsigned)C) ? kQuadOOB : q * 16u;
-    // LDS tile: row r = channel, 68-dword pitch; the column of rows 8m..8m+7 is XORed with
-    // 4*m so that the 32 lanes of a store group (8 quads x 4 bins) spread over the banks
-    // while rows stay 16-byte aligned for the ds_read_b128 of phase C.
-    const unsigned wswz = (q >> 1) * 4u;  // rows 4q..4q+3 -> m = q >> 1
-    const unsigned col = (lane & 15) * 4, row0 = lane >> 4;
-    const unsigned chans_here = min((unsigned)kChunk, (unsigned)C - k * kChunk);  // rows of this chunk < C
-    const v4f z4 = {0.f, 0.f, 0.f, 0.f};
-
-    unsigned g_lo = 0, g_hi = 0;          // groups of the current item (wave-uniform)
-    unsigned long long act_mask = 0;      // bins of the current item that are in a group
-
-    // phase A of one item: lane = bin, geometry -> sorted 16-byte tap records in LDS:
-    //   LO: {off_lt, off_2nd, w_lt, bin position}      (w_2nd = 1 - w_lt, see blend_lo)
-    //   HI: {off_lt, off_rt, off_lb, off_rb}, bin position in HP[]   (all four weights are 1/4)
-    // Offsets are byte offsets into the slice; kOOB reads as 0.0, which is what
-    // kernel.cu:116-126 substitutes for a tap outside the map.
-    auto geometry = [&](const Affine& A, unsigned t, unsigned p, unsigned& n_lo_groups,
-                        unsigned& n_hi_groups, unsigned long long& amask) {
-        uint4* const G = Gbuf + p * kRecs;
-        unsigned char* const HP = HPbuf + p * kRecs;
-        const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
-        const unsigned bin = t * kTileBins + lane;
-        const unsigned ph = fdiv(bin, div_pw);
-        const unsigned pw = bin - ph * (unsigned)pooled_width;
-        float bcx, bcy;
-        bool active = bin_centre(A, (int)ph, (int)pw, height, width, bcx, bcy);
-        active = active && bin < (unsigned)NB && batch_ok;
-        const float fx = floorf(bcx), fy = floorf(bcy);
-        const int x0 = f2i_sat(fx), x1 = f2i_sat(ceilf(bcx));
-        const int y0 = f2i_sat(fy), y1 = f2i_sat(ceilf(bcy));
-        const bool x0ok = x0 > 0 && x0 < width, x1ok = x1 > 0 && x1 < width;
-        const bool y0ok = y0 > 0 && y0 < height, y1ok = y1 > 0 && y1 < height;
-        const bool dx = active && x1 != x0, dy = active && y1 != y0;
-        // kernel.cu:116-126 validity; a tap that aliases lt (dx == 0 / dy == 0) is not loaded
-        const unsigned o00 = (unsigned)y0 * row_bytes + (unsigned)x0 * px_bytes;
-        const unsigned o_lt = (active && y0ok && x0ok) ? o00 : kOOB;
-        const unsigned o_rt = (dx && y0ok && x1ok) ? o00 + px_bytes : kOOB;
-        const unsigned o_lb = (dy && y1ok && x0ok) ? o00 + row_bytes : kOOB;
-        const unsigned o_rb = (dx && dy && y1ok && x1ok) ? o00 + row_bytes + px_bytes : kOOB;
-        const bool hi = dx && dy, lo = active && !hi;
-        const unsigned long long m_lo = __ballot(lo), m_hi = __ballot(hi);
-        const unsigned n_lo = __popcll(m_lo), n_hi = __popcll(m_hi);
-        // at least one LO group (all padding if need be): its loads are issued unconditionally,
-        // one item ahead, before the previous item's stores
-        n_lo_groups = n_lo ? (n_lo + kBinsPerIter - 1) / kBinsPerIter : 1u;
-        n_hi_groups = (n_hi + kBinsPerIter - 1) / kBinsPerIter;
-        amask = m_lo | m_hi;
-        const unsigned hi_base = n_lo_groups * kBinsPerIter;
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const unsigned idx = lo ? __popcll(m_lo & below) : hi_base + __popcll(m_hi & below);
-        const float rx = bcx - fx, ry = bcy - fy;
-        const float wlt = (1.0f - rx) * (1.0f - ry);  // kernel.cu:131
-        if (active) {
-            // LO: the one other distinct tap is rt (dx) or lb (dy); neither -> kOOB, weight 0
-            G[idx] = make_uint4(o_lt, dx ? o_rt : o_lb, hi ? o_lb : as_u(wlt), hi ? o_rb : lane);
-            HP[idx] = (unsigned char)lane;
-        }
-        // pad both classes to whole groups with records that load nothing and store nowhere
-        const unsigned pad_lo = hi_base - n_lo, pad_hi = n_hi_groups * kBinsPerIter - n_hi;
-        if (lane < pad_lo + pad_hi) {
-            const bool plo = lane < pad_lo;
-            const unsigned pidx = plo ? n_lo + lane : hi_base + n_hi + (lane - pad_lo);
-            G[pidx] = make_uint4(kOOB, kOOB, plo ? 0u : kOOB, plo ? kPadPos : kOOB);
-            HP[pidx] = (unsigned char)kPadPos;
-        }
-    };
-    // register sets 0 / 1: the depth-2 pipeline of phase B; sets 2 .. 2 + kEarly - 1: the first LO groups of
-    // an item, whose loads go out BEFORE the previous tile's stores (see the loop at the end)
-    uint4 ra[2 + kEarly];
-    unsigned hpos[2];
-    v4f lt[2 + kEarly], rt[2 + kEarly], lb[2], rbv[2];
-    auto fetch_lo = [&](unsigned p, unsigned grp, int s) { ra[s] = Gbuf[p * kRecs + grp * kBinsPerIter + b]; };
-    auto fetch_hi = [&](unsigned p, unsigned grp, int s) {
-        ra[s] = Gbuf[p * kRecs + grp * kBinsPerIter + b];
-        hpos[s] = HPbuf[p * kRecs + grp * kBinsPerIter + b];
-    };
-    auto issue_lo = [&](__amdgpu_buffer_rsrc_t rs, int s) {
-        // offsets are < 2^30 or kOOB = 2^31, q_bytes is < 128 or kQuadOOB = 2^30: every sum with an
-        // out-of-range term lies in [2^30, 2^32) -- beyond any slice (shape_ok), and it cannot wrap
-        lt[s] = buf_load(rs, ra[s].x + q_bytes);
-        rt[s] = buf_load(rs, ra[s].y + q_bytes);  // the bin's one other distinct tap, if any
-    };
-    auto issue_hi = [&](__amdgpu_buffer_rsrc_t rs, int s) {
-        lt[s] = buf_load(rs, ra[s].x + q_bytes);
-        rt[s] = buf_load(rs, ra[s].y + q_bytes);
-        lb[s] = buf_load(rs, ra[s].z + q_bytes);
-        rbv[s] = buf_load(rs, ra[s].w + q_bytes);
-    };
-    float* const t_row = T + (q * 4) * kTStride;
-    float* const t_pad = T + kChunk * kTStride + (lane & 31u);
-    auto put = [&](unsigned pos, v4f v) {
-        float* tw = pos < (unsigned)kTileBins ? t_row + (pos ^ wswz) : t_pad;
-        tw[0 * kTStride] = v.x;
-        tw[1 * kTStride] = v.y;
-        tw[2 * kTStride] = v.z;
-        tw[3 * kTStride] = v.w;
-    };
-    auto blend_lo = [&](int s) {
-        // At most two distinct pixels p (= lt) and p2, with weights w and 1 - w
-        // (w = 1: p alone; w = 1/2: p and its right OR lower neighbour; kernel.cu:131-134 with
-        // rx, ry in {0, 1/2}).  The reference adds all four terms (:138-141); the two that
-        // re-read p or p2 carry weight exactly 0.  So
-        //   taps finite      -> those terms add +-0 and the sum is  (0 + p*w) + p2*(1-w);
-        //   a tap non-finite -> the reference's 0 * tap is NaN, and so is its sum.
-        // The two-term sum is finite exactly when both taps are (both weights are non-zero and
-        // at most 1), so adding  v - v  (0, or NaN when v is not finite) reproduces the
-        // reference bit for bit in both cases.  A NaN weight (centre at infinity) gives NaN
-        // either way.
-        const float w = as_f(ra[s].z), w2 = 1.0f - w;
-        v4f v = z4;
-        v += lt[s] * w;
-        v += rt[s] * w2;
-        v += v - v;
-        put(ra[s].w, v);
-    };
-    auto blend_hi = [&](int s) {
-        // four distinct pixels: dx and dy, so rx = ry = 1/2 and every weight is 1/4
-        v4f v = z4;  // kernel.cu:136-141, four channels at a time
-        v += lt[s] * 0.25f;
-        v += rt[s] * 0.25f;
-        v += rbv[s] * 0.25f;
-        v += lb[s] * 0.25f;
-        put(hpos[s], v);
-    };
-    // An empty asm that "rewrites" the current group's taps: placed right after the next
-    // group's loads are issued, it pins the first use of the current taps (and with it the
-    // s_waitcnt) BEHIND that issue.  Without it the compiler hoists the first multiplies of the
-    // blend above the "more groups?" branch and waits before anything new is in flight.
-    auto pin_lo = [&](int s) { asm volatile("" : "+v"(lt[s]), "+v"(rt[s])); };
-    auto pin_hi = [&](int s) { asm volatile("" : "+v"(lt[s]), "+v"(rt[s]), "+v"(lb[s]), "+v"(rbv[s])); };
-
-    // phase C of one item: [rows < C] x [64 bins] -> 256-byte row segments
-    // `live` = false turns every store into an out-of-range one (dropped by the descriptor
-    // check) instead of branching around them: the instruction stream of the loop must be the
-    // same on every path, or the compiler's s_waitcnt counts -- which take the most
-    // conservative value where paths merge -- degrade to vmcnt(0) and every blend waits for
-    // the store acknowledgements.  (Also the ablation knob: dbg & 1 drops the output stores.)
-    auto store_tile = [&](unsigned n, unsigned t, unsigned long long cur_mask, bool live) {
-        live = live && !(dbg & 1);
-        if (ONHWC) {
-            // channels-last output (R, PH*PW, C): lane = (channel quad q, bin b) as in phase B; a
-            // store covers 8 bins x 128 B, the 32 channels of this chunk in each bin's 4*C-byte
-            // line.  The tile is read back along its columns (the mapping put() wrote it with).
-            float* obase = out + (size_t)n * NB * C;
-            const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, (unsigned)NB * (unsigned)C * 4u);
-            const bool q_ok = k * kChunk + q * 4 < (unsigned)C;
-#pragma unroll
-            for (int it8 = 0; it8 < kIters; ++it8) {
-                const unsigned bl = (unsigned)it8 * kBinsPerIter + b;   // bin within the tile
-                const float* tr = t_row + (bl ^ wswz);
-                const bool on = (cur_mask >> bl) & 1ull;
-                const v4f o = {on ? tr[0] : 0.f, on ? tr[kTStride] : 0.f, on ? tr[2 * kTStride] : 0.f,
-                               on ? tr[3 * kTStride] : 0.f};
-                const unsigned bin = t * kTileBins + bl;
-                const unsigned off = (bin * (unsigned)C + k * kChunk + q * 4u) * 4u;
-                const unsigned o_off = (live && q_ok && bin < (unsigned)NB) ? off : kOOB;
-                if (AUX == 2 && it8 == 0) buf_store<kMinorAux>(ws, o_off, o);
-                else buf_store<AUX>(ws, o_off, o);
-            }
-            return;
-        }
-        // descriptor over this (roi, chunk) block of the output: rows >= C fall out of range
-        float* obase = out + ((size_t)n * C + k * kChunk) * NB;
-        const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, chans_here * (unsigned)NB * 4u);
-        const unsigned bin0 = t * kTileBins + col;
-        // bins that were in no group (masked by pw > roi_pooled_width) are zero
-        const unsigned nib = (unsigned)(cur_mask >> col) & 15u;
-        const bool a0 = nib & 1u, a1 = nib & 2u, a2 = nib & 4u, a3 = nib & 8u;
-        // two halves of 4 row groups: 16 instead of 32 registers live across the LDS reads
-#pragma unroll
-        for (int hs = 0; hs < 2; ++hs) {
-            v4f v[kChunk / 8];
-#pragma unroll
-            for (int s4 = 0; s4 < kChunk / 8; ++s4) {
-                const unsigned r = (hs * (kChunk / 8) + s4) * 4 + row0;
-                v[s4] = *reinterpret_cast<const v4f*>(T + r * kTStride + (col ^ ((r >> 3) * 4u)));
-            }
-#pragma unroll
-            for (int s4 = 0; s4 < kChunk / 8; ++s4) {
-                const unsigned r = (hs * (kChunk / 8) + s4) * 4 + row0;
-                const unsigned off = (r * (unsigned)NB + bin0) * 4u;
-                const v4f o = {a0 ? v[s4].x : 0.f, a1 ? v[s4].y : 0.f, a2 ? v[s4].z : 0.f, a3 ? v[s4].w : 0.f};
-                if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
-                    // AUX == 2 (the shipped policy): the first of the tile's eight stores goes out
-                    // write-through (sc0 sc1), the other seven streaming (nt) -- see buf_store
-                    if (AUX == 2 && hs * (kChunk / 8) + s4 < MINOR)
-                        buf_store<kMinorAux>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);
-                    else
-                    buf_store<AUX>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);
-                } else {
-                    buf_store1<AUX>(ws, (live && bin0 + 0 < (unsigned)NB) ? off + 0 : kOOB, o.x);
-                    buf_store1<AUX>(ws, (live && bin0 + 1 < (unsigned)NB) ? off + 4 : kOOB, o.y);
-                    buf_store1<AUX>(ws, (live && bin0 + 2 < (unsigned)NB) ? off + 8 : kOOB, o.z);
-                    buf_store1<AUX>(ws, (live && bin0 + 3 < (unsigned)NB) ? off + 12 : kOOB, o.w);
-                }
-            }
-        }
-    };
-
-    // Software pipeline over the items of this wave.  gfx950 counts loads and stores with ONE
-    // in-order counter, so a load issued after a tile's stores cannot be consumed before those
-    // stores are acknowledged by the memory system (microseconds, with 256 MiB streaming out).
-    // Per iteration, with the tile of item i-1 complete in T and the records of item i in set p:
-    //   1. the first loads of item i are issued (they are AHEAD of the stores in the counter);
-    //   2. tile i-1 leaves: LDS -> registers -> 8 x 1 KiB streaming stores;
-    //   3. geometry of item i+1 -> record set p^1: ~250 instructions that depend on no memory
-    //      access, run while the stores drain;
-    //   4. phase B of item i -> T (its later groups do wait for the store acknowledgements).
-    unsigned cur = slot;
-    if (cur >= items) return;
-    unsigned n = fdiv(cur, div_tiles);
-    unsigned t = cur - n * (unsigned)ntiles;
-    unsigned p = 0;
-    unsigned n_prev = 0, t_prev = 0;
-    unsigned long long mask_prev = 0;
-    bool have_prev = false;
-    unsigned g_lo_next = 0, g_hi_next = 0;
-    unsigned long long mask_next = 0;
-    {
-        const Affine A = aff[n];
-        geometry(A, t, 0, g_lo, g_hi, act_mask);
-    }
-    int batch = aff[n].batch;
-    lds_wave_sync();
-
-    for (;;) {
-        const unsigned nxt = cur + nslots;
-        const bool has_next = nxt < items;
-        const unsigned n_next = has_next ? fdiv(nxt, div_tiles) : n;
-        const unsigned t_next = nxt - n_next * (unsigned)ntiles;
-        const Affine A_next = aff[n_next];  // scalar loads, in flight during steps 1-2
-
-        const bool batch_ok = batch >= 0 && batch < batch_size;
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(
-            map + (size_t)(batch_ok ? batch : 0) * lay.img_stride + (size_t)k * lay.chunk_stride, lay.slice_bytes);
-        // the first kEarly LO groups go out ahead of the stores, unconditionally (a record beyond the
-        // item's LO groups is a HI record, padding or stale: its offsets are in range or kOOB, the
-        // data is never used) -- straight-line code keeps the s_waitcnt counts exact
-#pragma unroll
-        for (int e = 0; e < kEarly; ++e) {
-            fetch_lo(p, e, 2 + e);
-            issue_lo(rs, 2 + e);
-        }
-        store_tile(n_prev, t_prev, mask_prev, have_prev);
-        lds_wave_sync();  // T has been read: free for this item's blends
-        if (has_next) geometry(A_next, t_next, p ^ 1u, g_lo_next, g_hi_next, mask_next);
-
-        // ---- phase B.  The early groups are blended first: their loads are OLDER than the stores, so
-        // they need no store acknowledgement; the next group's loads go out before that (again
-        // unconditionally).  Then the remaining LO groups and the HI groups; the loads of group g+1 are
-        // issued before group g is blended.  The loops are unrolled with an early exit, and the two
-        // exit paths end in different (empty) asm statements so that the compiler cannot merge their
-        // tails: each blend then has ONE predecessor and its s_waitcnt knows exactly how many younger
-        // loads are in flight.
-        fetch_lo(p, kEarly, 0);
-        issue_lo(rs, 0);
-#pragma unroll
-        for (int e = 0; e < kEarly; ++e) {
-            if ((unsigned)e < g_lo) {
-                pin_lo(2 + e);
-                blend_lo(2 + e);
-            }
-        }
-        if (g_lo > (unsigned)kEarly) {
-#pragma unroll
-            for (int it = kEarly; it < kMaxGroups; ++it) {
-                const int s = (it - kEarly) & 1;
-                if ((unsigned)(it + 1) < g_lo) {
-                    fetch_lo(p, it + 1, s ^ 1);
-                    issue_lo(rs, s ^ 1);
-                    pin_lo(s);
-                    blend_lo(s);
-                    asm volatile("; lo: more groups follow");
-                } else {
-                    blend_lo(s);
-                    asm volatile("; lo: last group");
-                    break;
-                }
-            }
-        }
-        if (g_hi > 0) {
-            fetch_hi(p, g_lo, 0);
-            issue_hi(rs, 0);
-#pragma unroll
-            for (int it = 0; it < kIters; ++it) {
-                const int s = it & 1;
-                if ((unsigned)(it + 1) < g_hi) {
-                    fetch_hi(p, g_lo + it + 1, s ^ 1);
-                    issue_hi(rs, s ^ 1);
-                    pin_hi(s);
-                    blend_hi(s);
-                    asm volatile("; hi: more groups follow");
-                } else {
-                    blend_hi(s);
-                    asm volatile("; hi: last group");
-                    break;
-                }
-            }
-        }
-        lds_wave_sync();  // T complete; record set p^1 complete
-        if (!has_next) {
-            store_tile(n, t, act_mask, true);
-            break;
-        }
-        n_prev = n;
-        t_prev = t;
-        mask_prev = act_mask;
-        have_prev = true;
-        cur = nxt;
-        n = n_next;
-        t = t_next;
-        batch = A_next.batch;
-        g_lo = g_lo_next;
-        g_hi = g_hi_next;
-        act_mask = mask_next;
-        p ^= 1u;
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// K1s (round 3): the hot kernel with its loads and its stores in DIFFERENT waves.  Same items, same
-// phases A / B / C, same LDS tile and records as rroi_fwd_tiled_kernel (NCHW crops only); a workgroup
-// is a gatherer wave (phase B: tap loads, blend, transpose) and a storer wave (phase C: the stores --
-// and phase A, the geometry of the next item, which depends on no memory access and fills the time the
-// storer would otherwise idle: ~310 instructions per tile in either wave).
-// Template parameters: VEC_STORE 16-byte stores (PH * PW % 4 == 0) | AUX cache policy of the stores | EARLY LO groups
-// issued before barrier 2 | MINOR write-through stores per tile | OCC waves per SIMD (__launch_bounds__) | HID HI
-// groups single-buffered (1), double-buffered unrolled (2) or rolled (3) | ONHWC channels-last crops | SHIFT crops
-// whose rows are not whole 64-byte sectors: runs of tiles and sector-aligned store windows (1: every row a multiple
-// of 16 bytes into its sector, 2: any offset; see drain_shift).  dbg: bit 0 drops the stores, bit 1 the tap loads
-// (ablations), bit 5 the reference-ABI launcher's mode, bits 8.. SHIFT's runs per (roi, chunk) block.
-// ------------------------------------------------------------------------------------
+constexpr int kStoreAux = 2;      // output stores stream (nt) ...
+constexpr int kMinorStores = 1;   // ... except this many of a tile's eight, which go out write-through (kMinorAux)
 // Workgroup barrier that orders LDS traffic only: s_barrier does not wait for vector memory, and unlike
 // __syncthreads() nothing here makes the compiler emit s_waitcnt vmcnt(0).
 __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -656,8 +282,7 @@ __device__ unsigned* g_wg_trace = nullptr;
 #define RROI_TRACE(i) do { } while (0)
 #endif
 
-template <bool VEC_STORE, int AUX, int EARLY = 2, int MINOR = 1, int OCC = 5, int HID = 2, bool ONHWC = false,
-          int SHIFT = 0>
+template <bool VEC_STORE, int EARLY, int OCC, int HID, bool ONHWC, int SHIFT>
 __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
@@ -870,8 +495,8 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                 const unsigned bin = t * kTileBins + bl;
                 const unsigned off = (bin * (unsigned)C + k * kChunk + q * 4u) * 4u;
                 const unsigned o_off = (live && q_ok && bin < (unsigned)NB) ? off : kOOB;
-                if (AUX == 2 && it8 < MINOR) buf_store<kMinorAux>(ws, o_off, o);
-                else buf_store<AUX>(ws, o_off, o);
+                if (it8 < kMinorStores) buf_store<kMinorAux>(ws, o_off, o);
+                else buf_store<kStoreAux>(ws, o_off, o);
             }
             return;
         }
@@ -896,15 +521,15 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             const unsigned off = (r * (unsigned)NB + bin0) * 4u;
             const v4f o = {a0 ? v[s4].x : 0.f, a1 ? v[s4].y : 0.f, a2 ? v[s4].z : 0.f, a3 ? v[s4].w : 0.f};
             if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
-                if (AUX == 2 && s4 < MINOR)
+                if (s4 < kMinorStores)
                     buf_store<kMinorAux>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);
                 else
-                    buf_store<AUX>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);
+                    buf_store<kStoreAux>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);
             } else {
-                buf_store1<AUX>(ws, (live && bin0 + 0 < (unsigned)NB) ? off + 0 : kOOB, o.x);
-                buf_store1<AUX>(ws, (live && bin0 + 1 < (unsigned)NB) ? off + 4 : kOOB, o.y);
-                buf_store1<AUX>(ws, (live && bin0 + 2 < (unsigned)NB) ? off + 8 : kOOB, o.z);
-                buf_store1<AUX>(ws, (live && bin0 + 3 < (unsigned)NB) ? off + 12 : kOOB, o.w);
+                buf_store1<kStoreAux>(ws, (live && bin0 + 0 < (unsigned)NB) ? off + 0 : kOOB, o.x);
+                buf_store1<kStoreAux>(ws, (live && bin0 + 1 < (unsigned)NB) ? off + 4 : kOOB, o.y);
+                buf_store1<kStoreAux>(ws, (live && bin0 + 2 < (unsigned)NB) ? off + 8 : kOOB, o.z);
+                buf_store1<kStoreAux>(ws, (live && bin0 + 3 < (unsigned)NB) ? off + 12 : kOOB, o.w);
             }
         }
     };
@@ -1023,8 +648,8 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             // float offset of position p0 within the (roi, chunk) block; never negative where `whole`
             const unsigned off = (r * (unsigned)NB + t * kTileBins + (unsigned)p0 - h) * 4u;
             const unsigned o_off = (live && whole && r < chans_here) ? off : kOOB;
-            if (AUX == 2 && s4 < MINOR) buf_store<kMinorAux>(ws, o_off, o[s4]);
-            else buf_store<AUX>(ws, o_off, o[s4]);
+            if (s4 < kMinorStores) buf_store<kMinorAux>(ws, o_off, o[s4]);
+            else buf_store<kStoreAux>(ws, o_off, o[s4]);
         }
         if (!interior && sub) {
 #pragma unroll
@@ -1032,8 +657,8 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                 const int pa = pl + (int)fi + 2 * ps, pb = (ph & ~3) + (int)fi + 2 * ps;
                 const bool oka = live && fr < chans_here && pa < ((pl + 3) & ~3) && pa < ph;
                 const bool okb = live && fr < chans_here && pb < ph && pb >= pl && (ph & ~3) >= ((pl + 3) & ~3);
-                buf_store1<AUX>(ws, oka ? (fr * (unsigned)NB + t * kTileBins + (unsigned)pa - fh) * 4u : kOOB, fix[ps]);
-                buf_store1<AUX>(ws, okb ? (fr * (unsigned)NB + t * kTileBins + (unsigned)pb - fh) * 4u : kOOB, fix[2 + ps]);
+                buf_store1<kStoreAux>(ws, oka ? (fr * (unsigned)NB + t * kTileBins + (unsigned)pa - fh) * 4u : kOOB, fix[ps]);
+                buf_store1<kStoreAux>(ws, okb ? (fr * (unsigned)NB + t * kTileBins + (unsigned)pb - fh) * 4u : kOOB, fix[2 + ps]);
             }
         }
         if (flush && left > kTileBins - 15) {
@@ -1050,13 +675,13 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                 w.w = Cy[fr * 16u + ((unsigned)(16 + p0 + 3 - (int)fh) & 15u)];
                 const unsigned off = (fr * (unsigned)NB + (t + 1) * kTileBins + (unsigned)p0 - fh) * 4u;
                 const bool okr = live && fr < chans_here;
-                buf_store<AUX>(ws, (okr && p0 + 4 <= pend) ? off : kOOB, w);
+                buf_store<kStoreAux>(ws, (okr && p0 + 4 <= pend) ? off : kOOB, w);
                 // the piece that holds the end of the valid positions goes out float by float
                 const bool part = okr && p0 < pend && p0 + 4 > pend;
                 if (sub) {
-                    buf_store1<AUX>(ws, (part && p0 + 0 < pend) ? off + 0u : kOOB, w.x);
-                    buf_store1<AUX>(ws, (part && p0 + 1 < pend) ? off + 4u : kOOB, w.y);
-                    buf_store1<AUX>(ws, (part && p0 + 2 < pend) ? off + 8u : kOOB, w.z);
+                    buf_store1<kStoreAux>(ws, (part && p0 + 0 < pend) ? off + 0u : kOOB, w.x);
+                    buf_store1<kStoreAux>(ws, (part && p0 + 1 < pend) ? off + 4u : kOOB, w.y);
+                    buf_store1<kStoreAux>(ws, (part && p0 + 2 < pend) ? off + 8u : kOOB, w.z);
                 }
             }
         }
@@ -1248,15 +873,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                 }
             }
         }
-        if (HID == 1) {
-            // HI groups one at a time (no second register set: 20 VGPRs fewer)
-#pragma unroll 1
-            for (unsigned it = 0; it < g_hi; ++it) {
-                fetch_hi(p, g_lo + it, 0);
-                issue_hi(rs, 0);
-                blend_hi(0);
-            }
-        } else if (HID == 3) {
+        if (HID == 3) {
             // two register sets, a ROLLED loop over pairs of groups (the unrolled form costs 28 VGPRs more)
             if (g_hi > 0) {
                 fetch_hi(p, g_lo, 0);

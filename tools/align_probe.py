@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Crops whose rows are not multiples of 64 bytes (PH*PW % 16 != 0): the forward gather by store policy
-(explore build: rroi_align_debug_set_store_aux) and channel count.  us per gather launch."""
+"""Crops whose rows are not multiples of 64 bytes (PH*PW % 16 != 0): the forward gather with the SHIFT kernels where
+they pay (1), with the strided items only (0) and with SHIFT forced (2), by pooled size, channel count and ROI count
+(explore build: rroi_align_debug_set_fwd_shift).  us per gather launch."""
 import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,13 +40,6 @@ def case(C, ph, pw, R=512, H=160, W=160):
         lib.rroi_align_debug_set_fwd_shift(shift, -1, -1)
         res.append(f"shift {shift}: {timed(lambda: go(2)):6.1f}")
     lib.rroi_align_debug_set_fwd_shift(1, -1, -1)
-    if os.environ.get("RROI_ALIGN_AUX"):
-        lib.rroi_align_debug_set_fwd_shift(0, -1, -1)
-        for aux in (2, 0, 16, 3):
-            lib.rroi_align_debug_set_store_aux(aux)
-            res.append(f"aux {aux:2d}: {timed(lambda: go(2)):6.1f}")
-        lib.rroi_align_debug_set_store_aux(2)
-        lib.rroi_align_debug_set_fwd_shift(1, -1, -1)
     print(f"R={R:4d} C={C:3d} {ph}x{pw} rows of {ph * pw * 4} B (mod 64 = {ph * pw * 4 % 64:2d}), out {R * C * ph * pw * 4 / 1e6:6.1f} MB | " + "  ".join(res))
 if os.environ.get("RROI_ALIGN_PMC"):   # a few launches of four cases for a counter pass
     def timed(fn, warm=2, n=3):   # noqa: F811

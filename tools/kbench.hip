@@ -375,25 +375,6 @@ int main(int argc, char** argv)
         report("  step: prologue + store-only tile pattern 1/8", T.us([&] { for (int i = 0; i < 20; ++i) { stage(1); hipLaunchKernelGGL((k_store_mix<0, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 8); } }, 50, 5) / 20, MB);
         return 0;
     }
-    if (argc > 1 && std::string(argv[1]) == "early") {
-        // A/B over the number of LO groups whose loads go out ahead of the previous tile's stores
-        auto stage = [&](int s) {
-            int rc = rroi_align_forward_stages_hip(feat, 0, 0.25f, 1, R, H, W, C, PH, PW, rois_d, out, ws, wsb, 2, s, 0);
-            if (rc != 1) { fprintf(stderr, "stage rc=%d\n", rc); exit(1); }
-        };
-        for (int i = 0; i < 300; ++i) stage(3);
-        CK(hipDeviceSynchronize());
-        for (int rep = 0; rep < 3; ++rep)
-            for (int e : {1, 2, 3, 4, 5}) {
-                rroi_align_debug_set_fwd_early(e);
-                char nm[96];
-                snprintf(nm, 96, "rep %d early=%d: gather alone (200 launches)", rep, e);
-                report(nm, T.us([&] { stage(2); }, 200, 20), MB);
-                snprintf(nm, 96, "rep %d early=%d: whole step, 50 x 20 steps", rep, e);
-                report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 50, 5) / 20, MB);
-            }
-        return 0;
-    }
     if (argc > 1 && std::string(argv[1]) == "xatom") {
         const unsigned nlines = 3200;   // 160 x 160 map in 8 x 4 key tiles = 800 lines per image; x4 for spread
         unsigned *cnt, *sink;
@@ -512,15 +493,12 @@ int main(int argc, char** argv)
             CK(hipMemcpy(rois_d, pr.data(), pr.size() * 4, hipMemcpyHostToDevice));
             const char* nm4[4] = {"as generated", "sorted by centre y", "sorted by Morton code of the centre (8 px cells)", "32-row bands, x inside"};
             char nm[128];
-            for (int minor : {1, 2, 3}) {   // write-through stores per tile: a sorted order leaves the L2 more room
-                rroi_align_debug_set_fwd_minor(minor);
-                stage(3);
-                snprintf(nm, 128, "gather, %d/8 write-through, ROIs %s", minor, nm4[mode]);
-                report(nm, T.us([&] { stage(2); }, 200, 20), MB);
-                snprintf(nm, 128, "  whole step, %d/8 write-through, ROIs %s", minor, nm4[mode]);
-                report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 50, 5) / 20, MB);
-            }
-            rroi_align_debug_set_fwd_minor(1);
+            // (round 2 also swept the write-through stores per tile here; that template parameter is a constant now)
+            stage(3);
+            snprintf(nm, 128, "gather, ROIs %s", nm4[mode]);
+            report(nm, T.us([&] { stage(2); }, 200, 20), MB);
+            snprintf(nm, 128, "  whole step, ROIs %s", nm4[mode]);
+            report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 50, 5) / 20, MB);
         }
         return 0;
     }
@@ -561,28 +539,18 @@ int main(int argc, char** argv)
         };
         for (int i = 0; i < 300; ++i) stage(3);  // clocks
         CK(hipDeviceSynchronize());
-        for (int aux : {2, 3, 16, 0}) {
-            rroi_align_debug_set_store_aux(aux);
-            char nm[96];
-            snprintf(nm, 96, "gather, store aux=%d", aux);
-            report(nm, T.us([&] { stage(2); }, 100), MB);
-            const double pipe = T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 10, 2) / 20;
-            snprintf(nm, 96, "pipeline step, store aux=%d", aux);
-            report(nm, pipe, MB);
-        }
-        rroi_align_debug_set_store_aux(2);
-        for (int wpc : {12, 13, 14}) {
-            rroi_align_debug_set_waves_per_cu(wpc);
+        for (int wpc : {10, 12}) {
+            rroi_align_debug_set_split_wgs_per_cu(wpc);
             for (int dbg : {0, 1}) {
                 rroi_align_debug_set_fwd_dbg(dbg);
                 char nm[96];
-                snprintf(nm, 96, "gather %d waves/CU ablation=%d", wpc, dbg);
+                snprintf(nm, 96, "gather %d workgroups/CU ablation=%d", wpc, dbg);
                 report(nm, T.us([&] { stage(2); }, 100), MB);
             }
             rroi_align_debug_set_fwd_dbg(0);
             const double pipe = T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 10, 2) / 20;
             char nm[96];
-            snprintf(nm, 96, "pipeline step waves/CU=%d", wpc);
+            snprintf(nm, 96, "pipeline step workgroups/CU=%d", wpc);
             report(nm, pipe, MB);
         }
         return 0;
@@ -669,22 +637,21 @@ int main(int argc, char** argv)
     }
     rroi_align_debug_set_prologue_aux(0);
     rroi_align_debug_set_prologue_blocks(3);
-    rroi_align_debug_set_store_aux(2);
     rroi_align_debug_set_prologue_aux(0);
-    for (int wpc : {12, 13, 14}) {
-        rroi_align_debug_set_waves_per_cu(wpc);
+    for (int wpc : {10, 12}) {
+        rroi_align_debug_set_split_wgs_per_cu(wpc);
         char nm[96];
         for (int dbg : {0, 1}) {
             rroi_align_debug_set_fwd_dbg(dbg);
-            snprintf(nm, 96, "gather %d waves/CU ablation=%d", wpc, dbg);
+            snprintf(nm, 96, "gather %d workgroups/CU ablation=%d", wpc, dbg);
             report(nm, T.us([&] { stage(2); }, 100), MB);
         }
         rroi_align_debug_set_fwd_dbg(0);
         const double pipe = T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 10, 2) / 20;
-        snprintf(nm, 96, "pipeline step waves/CU=%d", wpc);
+        snprintf(nm, 96, "pipeline step workgroups/CU=%d", wpc);
         report(nm, pipe, MB);
     }
-    rroi_align_debug_set_waves_per_cu(12);
+    rroi_align_debug_set_split_wgs_per_cu(12);
     report("product all", T.us([&] { stage(3); }, 100), MB);
 
     // raw gather bandwidth out of L2 / L1 (per-XCD slice sized regions)
