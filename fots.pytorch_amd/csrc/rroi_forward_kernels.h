@@ -759,7 +759,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
 #ifdef RROI_EXPLORE
             // ablation (dbg & 256): the workgroup's FIRST item costs nothing -- no geometry, no taps (its tile is zeros):
             // an upper bound on what any shortening of the launch's start-up chain can gain
-            geometry(A, pt, pp, gl, gh, m, ((dbg & 256) && first_plan) ? 64u : cur_pre ? 48u : 0u);
+            geometry(A, pt, pp, gl, gh, m, (!SHIFT && (dbg & 256) && first_plan) ? 64u : cur_pre ? 48u : 0u);   // (SHIFT: bits 8.. are the runs per block)
             first_plan = false;
 #else
             geometry(A, pt, pp, gl, gh, m, cur_pre ? 48u : 0u);
