@@ -86,8 +86,6 @@ struct Tuning {
     // -> 12 workgroups per CU; a larger grid would run its surplus as a second round
     int split_wgs_per_cu = 12;
     int fwd_shift = 1;            // 1: crops with PH * PW % 16 != 0 take the SHIFT forms where they pay; 2: always; 0: never
-    int shift_pre = 1;            // SHIFT = 1: runs that start inside a block begin with a pre item
-    int shift_parts = 0;          // > 0 forces the runs per (roi, chunk) block
     int shift_wgs_per_cu = 0;     // > 0 overrides the SHIFT kernels' workgroups per CU
     int fwd_dbg = 0;              // ablations: 1 = skip output stores, 2 = all taps out of range, 256 = free first item
     int prologue_blocks_per_cu = 3;
@@ -324,57 +322,36 @@ enum class FwdKernel {
     kStrided,        // every n-th (roi, tile) item per workgroup, 16-byte stores: crops whose rows are whole sectors
     kStridedScalar,  // the same with dword stores (PH * PW % 4 != 0) -- small problems only, see shift_pays
     kChannelsLast,   // channels-last crops (R, PH, PW, C)
-    kShift16,        // SHIFT = 1: runs of tiles, every row a multiple of 16 bytes into its sector
-    kShiftAny,       // SHIFT = 2: runs of tiles, any row offset (also crops that start 4 bytes off)
+    kShift,          // SHIFT: overlapped tiles, sector-aligned store windows -- crops whose rows are not whole sectors
 };
 struct ForwardPlan {
     FwdKernel kernel;
     int grid;
-    int dbg;   // the kernel's flag word (see its header comment)
+    int ntiles;   // tiles per (roi, chunk) block: ceil(NB / 64), SHIFT: ceil(NB / 48)
+    int dbg;      // the kernel's flag word (see its header comment)
 };
 
-ForwardPlan plan_forward_gather(int num_rois, int channels, int NB, int ntiles, int nchunks, bool out_nhwc,
-                                bool launcher_rest, bool out_aligned16)
+constexpr int kShiftWgsPerCu = 12;   // the SHIFT instantiation: <= 80 VGPRs under __launch_bounds__(128, 6), 12.4 KB of LDS
+constexpr int kShiftOwnBins = kTileBins - 16;   // bins a SHIFT tile advances by (it gathers 64: kOwnBins in the kernel)
+
+ForwardPlan plan_forward_gather(int num_rois, int channels, int NB, int nchunks, bool out_nhwc, bool launcher_rest)
 {
-    const long items = (long)num_rois * ntiles;
     const int base_dbg = (g_tune.fwd_dbg & ~0xe0) | (launcher_rest ? 32 : 0);   // bits 5-7 are the host's
+    const int ntiles = ceil_div(NB, kTileBins);
     if (out_nhwc)   // (91 VGPRs -> five waves per SIMD: 10 workgroups per CU are resident, and no more are launched)
-        return {FwdKernel::kChannelsLast, tiled_grid(items, nchunks, 10), g_tune.fwd_dbg & ~0xe0};
-    // Crops whose rows are not whole 64-byte sectors (PH * PW % 16 != 0) take the SHIFT forms: a (roi, chunk) block of
-    // ntiles tiles is cut into `parts` runs for the workgroups of its chunk.  Every cut costs two partial sectors per
-    // channel row, every run shorter than the block buys parallelism: measured (tools/align_probe.py, 11 x 100 and
-    // 11 x 83 crops, R = 8 ... 2048, C = 64 / 256) the best cut is about one run per workgroup while the ROIs are fewer
-    // than the workgroups of a chunk -- 2 for R = 512 on 1280 slots (39 us; 1: 49, 3: 46, 9: 51), 6 for R = 128 on 1024
-    // (18; 2: 32, 15: 24) -- and none beyond.  With PRE items (SHIFT = 1 only: a run that starts inside a block samples
-    // the last 16 columns of the tile before it first, stores nothing of them, and so starts on a whole sector; the run
-    // before it has nothing to flush) a cut costs a quarter of a tile's work instead of partial sectors, and six runs
-    // per block are as good as or better than the best cut without them everywhere measured (R = 2048, C = 64,
-    // 11 x 100: 124.5 against 135.5 us; R = 512: 35.7 against 38.0; profiles/r03_align_parts.txt).  The SHIFT = 2 storer
-    // is the heavier wave already: there they cost more than they save (R = 512, 11 x 83: 51 against 42 us).
-    auto shift_parts = [&](int wgs_per_cu, bool pre) {
-        if (g_tune.shift_parts > 0) return std::min(g_tune.shift_parts, ntiles);
-        const long per_roi = std::max(1L, (long)num_cus() * wgs_per_cu / nchunks) / std::max(1, num_rois);
-        long m = pre ? std::max(6L, 3 * per_roi / 4) : per_roi <= 3 ? per_roi : 3 * per_roi / 4;
-        m = std::max(1L, std::min<long>(m, ntiles));
-        while (m > 1 && (m - 1) * ceil_div(ntiles, (int)m) >= ntiles) --m;   // no empty last part
-        return (int)m;
-    };
-    // small problems stay with the strided items (latency-bound: 12 workgroups per CU all busy beats whole sectors) --
-    // from 5 workgroups of a chunk per roi up when the rows are multiples of 16 bytes (R = 128, C = 64, 11 x 100: 15.3
-    // against 15.1 us; R = 32: 6.3 against 8.2), from 32 up otherwise, where the strided form stores dwords (R = 32,
-    // C = 64, 11 x 83: 10.0 against 9.2; R = 8: 5.1 against 7.3; R = 128: 51 against 18)
-    const long slots_per_roi = std::max(1L, (long)num_cus() * g_tune.split_wgs_per_cu / nchunks) / std::max(1, num_rois);
-    const bool shift_pays = g_tune.fwd_shift == 2 || slots_per_roi < (NB % 4 == 0 ? 5 : 32);
-    if (g_tune.fwd_shift && (NB % 16 != 0 || g_tune.fwd_shift == 2) && shift_pays) {
-        const bool s16 = NB % 4 == 0 && out_aligned16;   // every row starts a multiple of 16 bytes into its sector
-        const int wpc = g_tune.shift_wgs_per_cu > 0 ? g_tune.shift_wgs_per_cu : s16 ? 10 : 8;
-        const bool pre = g_tune.shift_pre && s16;
-        const int sp = shift_parts(wpc, pre);
-        return {s16 ? FwdKernel::kShift16 : FwdKernel::kShiftAny, tiled_grid((long)num_rois * sp, nchunks, wpc),
-                (base_dbg & 63) | (sp > 1 && pre ? 64 : 0) | (sp << 8)};   // (bits 8.. = the runs per block)
+        return {FwdKernel::kChannelsLast, tiled_grid((long)num_rois * ntiles, nchunks, 10), ntiles, g_tune.fwd_dbg & ~0xe0};
+    // Crops whose rows are not whole 64-byte sectors (PH * PW % 16 != 0) take the SHIFT form: sector-aligned store windows
+    // over OVERLAPPED tiles (a tile advances by 48 bins and gathers 64, rroi_forward_kernels.h), items dealt every n-th
+    // like the strided form's.  It costs 4 / 3 of the gather work per byte and was never slower than the strided items on
+    // such crops, from R = 8 to R = 2048 (tools/align_probe.py, profiles/r04_align_probe.txt: R = 32, C = 64, 11 x 83: 6.6
+    // against 9.4 us; R = 128, 11 x 100: 13.7 against 16.5; R = 512, 11 x 83: 40 against 209)
+    if (g_tune.fwd_shift && (NB % 16 != 0 || g_tune.fwd_shift == 2)) {
+        const int wpc = g_tune.shift_wgs_per_cu > 0 ? g_tune.shift_wgs_per_cu : kShiftWgsPerCu;
+        const int nt = ceil_div(NB, kShiftOwnBins);
+        return {FwdKernel::kShift, tiled_grid((long)num_rois * nt, nchunks, wpc), nt, base_dbg};
     }
-    return {NB % 4 == 0 ? FwdKernel::kStrided : FwdKernel::kStridedScalar, tiled_grid(items, nchunks, g_tune.split_wgs_per_cu),
-            base_dbg};
+    return {NB % 4 == 0 ? FwdKernel::kStrided : FwdKernel::kStridedScalar,
+            tiled_grid((long)num_rois * ntiles, nchunks, g_tune.split_wgs_per_cu), ntiles, base_dbg};
 }
 
 // ------------------------------------------------------------------------------------
@@ -637,7 +614,8 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         if (st != 1) return st;
     }
     if (stages & RROI_STAGE_GATHER) {
-        const int ntiles = ceil_div(NB, kTileBins);
+        const ForwardPlan plan = plan_forward_gather(num_rois, channels, NB, nchunks, out_nhwc, launcher_rest);
+        const int ntiles = plan.ntiles;
         if ((long)num_rois * ntiles >= (1L << 31)) return 0;
         SliceLayout lay;
         if (zero_copy) {
@@ -654,8 +632,6 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
             lay.img_stride = lay.chunk_stride * (unsigned)nchunks;
         }
         const FastDiv dt = make_fastdiv((unsigned)ntiles), dp = make_fastdiv((unsigned)pooled_width);
-        const ForwardPlan plan = plan_forward_gather(num_rois, channels, NB, ntiles, nchunks, out_nhwc, launcher_rest,
-                                                     reinterpret_cast<size_t>(top_data) % 16 == 0);
         // the shipped instantiations of rroi_fwd_split_kernel<VEC_STORE, EARLY, OCC, HID, ONHWC, SHIFT>, one per FwdKernel
 #define RROI_GATHER(...)                                                                                              \
     hipLaunchKernelGGL((rroi_fwd_split_kernel<__VA_ARGS__>), dim3(plan.grid), dim3(2 * kWave), 0, stream, map, ws.aff, \
@@ -665,8 +641,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         case FwdKernel::kStrided:       RROI_GATHER(true, 0, 6, 3, false, 0); break;   // 62-64 VGPRs, 12.1 KB of LDS: 12 per CU
         case FwdKernel::kStridedScalar: RROI_GATHER(false, 0, 6, 3, false, 0); break;
         case FwdKernel::kChannelsLast:  RROI_GATHER(true, 2, 5, 2, true, 0); break;    // 91 VGPRs: 10 per CU
-        case FwdKernel::kShift16:       RROI_GATHER(true, 0, 5, 3, false, 1); break;   // 96 VGPRs, 14.2 KB of LDS: 10 per CU
-        case FwdKernel::kShiftAny:      RROI_GATHER(true, 0, 4, 3, false, 2); break;   // 117 VGPRs: 8 per CU
+        case FwdKernel::kShift:         RROI_GATHER(true, 0, 6, 3, false, 1); break;    // 79 VGPRs, 12.4 KB of LDS: 12 per CU
         }
 #undef RROI_GATHER
     }

@@ -312,9 +312,14 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // tile pitch), which admits 14 waves per CU: 12 waves 47.2 us, 13 48.0, 14 48.5 (tools/kbench abl)
     // -- the kernel is bound by the write path, not by latency -- and the spare-column writes are
     // 4-way bank-conflicted (SQ_LDS_BANK_CONFLICT 40 % instead of 32 % of the LDS cycles): not kept.
-    // (SHIFT: plus the carried groups, 16 floats per channel row, behind the tile)
-    constexpr unsigned kCyBase = kChunk * kTStride + 3 * kTStride + 32;
-    __shared__ __attribute__((aligned(16))) float T[kCyBase + (SHIFT ? kChunk * 16 : 0)];
+    // SHIFT: the tile is BIN-MAJOR instead -- T[lane's bin * 32 + channel], 64 gathered bins of which the LAST 48 are the
+    // tile's own (the first 16 are the tile before's last: every item is self-contained, see drain_shift); row 64 takes
+    // the padding records, rows 65..79 are never written (a window position beyond the gathered bins reads them and
+    // is never stored).  10240 B; with the records 12720 B = 10 granules, like the channel-major tile
+    constexpr unsigned kBmRows = kTileBins + 16;
+    constexpr int kOwnBins = SHIFT ? kTileBins - 16 : kTileBins;   // bins a tile stores / advances by
+    static_assert(SHIFT == 0 || SHIFT == 1, "SHIFT is a flag");
+    __shared__ __attribute__((aligned(16))) float T[SHIFT ? kBmRows * kChunk : kChunk * kTStride + 3 * kTStride + 32];
     // tap records of two items: item i+1 is sampled out of one set while the other is being
     // built for item i+2
     constexpr int kRecs = kMaxGroups * kBinsPerIter;
@@ -358,13 +363,18 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                         unsigned& n_hi_groups, unsigned long long& amask, unsigned min_lane = 0u) {
         uint4* const G = Gbuf + p * kRecs;
         unsigned char* const HP = HPbuf + p * kRecs;
+        // where phase B puts the bin: the lane's index -- its column of the channel-major tile, or (SHIFT) its row of the
+        // bin-major tile; kPadPos = 64: nowhere / row 64
+        auto tile_pos = [](unsigned lane_of_bin) -> unsigned { return lane_of_bin; };
         const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
-        const unsigned bin = t * kTileBins + lane;
+        // SHIFT: lanes 0..15 are the 16 bins in front of the tile's own 48 (negative for the first tile of a row)
+        const int sbin = (int)(t * (unsigned)kOwnBins + lane) - (SHIFT ? 16 : 0);
+        const unsigned bin = (unsigned)max(sbin, 0);
         const unsigned ph = fdiv(bin, div_pw);
         const unsigned pw = bin - ph * (unsigned)pooled_width;
         float bcx, bcy;
         bool active = bin_centre(A, (int)ph, (int)pw, height, width, bcx, bcy);
-        active = active && bin < (unsigned)NB && batch_ok && lane >= min_lane;
+        active = active && sbin >= 0 && bin < (unsigned)NB && batch_ok && lane >= min_lane;
         const float fx = floorf(bcx), fy = floorf(bcy);
         const int x0 = f2i_sat(fx), x1 = f2i_sat(ceilf(bcx));
         const int y0 = f2i_sat(fy), y1 = f2i_sat(ceilf(bcy));
@@ -392,16 +402,16 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         const float wlt = (1.0f - rx) * (1.0f - ry);  // kernel.cu:131
         if (active) {
             // LO: the one other distinct tap is rt (dx) or lb (dy); neither -> kOOB, weight 0
-            G[idx] = make_uint4(o_lt, dx ? o_rt : o_lb, hi ? o_lb : as_u(wlt), hi ? o_rb : lane);
-            HP[idx] = (unsigned char)lane;
+            G[idx] = make_uint4(o_lt, dx ? o_rt : o_lb, hi ? o_lb : as_u(wlt), hi ? o_rb : tile_pos(lane));
+            HP[idx] = (unsigned char)tile_pos(lane);
         }
         // pad both classes to whole groups with records that load nothing and store nowhere
         const unsigned pad_lo = hi_base - n_lo, pad_hi = n_hi_groups * kBinsPerIter - n_hi;
         if (lane < pad_lo + pad_hi) {
             const bool plo = lane < pad_lo;
             const unsigned pidx = plo ? n_lo + lane : hi_base + n_hi + (lane - pad_lo);
-            G[pidx] = make_uint4(kOOB, kOOB, plo ? 0u : kOOB, plo ? kPadPos : kOOB);
-            HP[pidx] = (unsigned char)kPadPos;
+            G[pidx] = make_uint4(kOOB, kOOB, plo ? 0u : kOOB, plo ? tile_pos(kPadPos) : kOOB);
+            HP[pidx] = (unsigned char)tile_pos(kPadPos);
         }
     };
     // register sets 0 / 1: the depth-2 pipeline of phase B; sets 2 .. 2 + kEarly - 1: the first LO groups of
@@ -429,6 +439,10 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     float* const t_row = T + (q * 4) * kTStride;
     float* const t_pad = T + kChunk * kTStride + (lane & 31u);
     auto put = [&](unsigned pos, v4f v) {
+        if (SHIFT) {   // bin-major tile: the lane's four channels of the bin are one 16-byte piece of the bin's row
+            *reinterpret_cast<v4f*>(reinterpret_cast<char*>(T) + ((pos << 7) + (q << 4))) = v;
+            return;
+        }
         float* tw = pos < (unsigned)kTileBins ? t_row + (pos ^ wswz) : t_pad;
         tw[0 * kTStride] = v.x;
         tw[1 * kTStride] = v.y;
@@ -538,151 +552,98 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // starts 16, 32 or 48 bytes into a 64-byte sector ends in one too: two partial sectors per row and tile, each
     // completed later by ANOTHER workgroup -- and HBM pays for a partial sector with a read-modify-write
     // (tools/align_probe.py: 11 x 100 crops 58 us against 28 us for 11 x 96; PH * PW % 4 != 0, where the stores
-    // were dwords: 215 us).  Here a workgroup owns a RUN of consecutive tiles of one (roi, chunk) block and
-    // every row's store window is shifted left by h = (the row's float offset in memory) mod 16, so that it starts
-    // on a sector: the h columns that fall out on the right are CARRIED in LDS (Cy: the previous tile's last four
-    // 4-float groups per row) into the next tile's window.  Partial sectors are left at the ends of a row and of a
-    // run only.  p = j + h is a float's position in the window, j its column in the tile (j < 0: carried).
-    // Between the barriers the storer does what drain_tile does -- one 16-byte LDS read per row set, of the group
-    // its window starts in (two when h is not a multiple of 4: the window then straddles two groups) -- so the
-    // gatherer waits no longer for T than without the shift; masks, the sub-group shift and the carry follow.
-    float* const Cy = T + kCyBase;
-    auto grp_idx = [&](unsigned r, int g) -> unsigned {   // float index in T[] of 4-float group g of row r
-        return g >= 0 ? r * kTStride + ((((unsigned)g) ^ (r >> 3)) << 2) : kCyBase + r * 16u + (unsigned)(4 + g) * 4u;
-    };
-    auto drain_shift = [&](unsigned n, unsigned t, unsigned long long cur_mask, bool skip, bool carry_ok, bool flush) {
-        const unsigned L = lane & 15u;
+    // were dwords: 215 us).  So every channel row's store WINDOW is shifted left by h = (the row's float offset in
+    // memory) mod 16 -- the crops' own base address included: window position p of tile t is bin 48 t + p - h of the
+    // row, every window starts on a sector and every 16-byte piece a lane stores is aligned.  Partial sectors are
+    // left at the two ends of a ROW only.
+    // Round 4: OVERLAPPED tiles.  A tile advances by 48 bins and gathers 64: its own 48 and the 16 in front of them,
+    // which is all a window shifted by h <= 15 can reach -- so an item needs nothing from its neighbour, items are
+    // dealt to the workgroups every n-th like the strided kernel's, and neighbouring tiles of a row are written at
+    // the same time by neighbouring workgroups.  (Round 3 CARRIED the h bins from tile to tile in LDS: a workgroup
+    // walked a run of consecutive tiles, so every 256 bytes of a row were written microseconds after their
+    // neighbours -- isolated DRAM accesses; with the store pattern alone the kernel took 131 of 150 us, and runs, pre
+    // items, cuts and flushes were half of its code.)  The price is 64 / 48 of the gather work per stored byte.
+    // The tile is bin-major for this -- T[lane's bin * 32 + channel], a bin's 32 channels one 128-byte row -- and the
+    // storer reads it with lane = (channel, piece):
+    //   * the gatherer writes a lane's four channels of a bin as ONE ds_write_b128 (the channel-major tile takes four
+    //     ds_write_b32); the eight lanes of a bin fill its row: no bank conflict, no swizzle;
+    //   * rows r and r + 16 of a chunk have the same h (16 NB is a multiple of 16), so a storer lane that serves the
+    //     channels ch16 and ch16 + 16 has ONE h, and every element it reads -- window positions 16 s + 4 pcl + e of
+    //     those two channels -- sits at a compile-time offset from ONE address: 32 ds_read_b32 with immediates, no
+    //     address arithmetic, whatever h is (round 3 rebuilt every window of a channel-major tile with a funnel of
+    //     selects from two ds_read_b128 per row set: two kernels, 96 / 117 VGPRs, 10 / 8 workgroups per CU);
+    //   * a wave store instruction covers 16 channel rows x one whole 64-byte sector (4 lanes x 16 B); a tile is three
+    //     sectors per row -- four in the last tile of a row, whose window runs on to the row's end.  (The strided
+    //     kernel's shape, 4 rows x 256 B per instruction, was built too -- lane = (channel of four, piece of sixteen) on
+    //     a quad-swizzled tile, two addresses and three selects per piece: 145 against 147 us at C = 256, 11 x 100, with
+    //     a quarter more instructions in the storer; not kept.  profiles/r04_shift_forms.md)
+    auto drain_shift = [&](unsigned n, unsigned t, unsigned long long cur_mask, bool skip) {
+        const unsigned ch16 = lane & 15u, pcl = lane >> 4;
         const unsigned nb15 = (unsigned)NB & 15u;
         // float index of (roi n, first channel of the chunk, bin 0), modulo a sector -- out's own alignment included
         const unsigned h0 = (((unsigned)(reinterpret_cast<size_t>(out) >> 2) & 15u) +
                              (((n & 15u) * ((unsigned)C & 15u) + ((k * kChunk) & 15u)) & 15u) * nb15) & 15u;
-        // SHIFT == 1: every row's h is a multiple of 4 (PH * PW % 4 == 0 and `out` 16-byte aligned: the host checks)
-        constexpr bool sub = SHIFT == 2;
-        const int left = NB - (int)(t * kTileBins);            // columns of this tile that are bins (>= 1)
-        const bool interior = carry_ok && left >= kTileBins;   // every position of every window is a bin of this run
-        auto masked = [&](v4f x, int g) -> v4f {               // bins in no group are zero; carried groups already are
-            const unsigned m = g >= 0 ? (unsigned)(cur_mask >> (4 * g)) & 15u : 15u;
-            return v4f{(m & 1u) ? x.x : 0.f, (m & 2u) ? x.y : 0.f, (m & 4u) ? x.z : 0.f, (m & 8u) ? x.w : 0.f};
-        };
-        auto tile_at = [&](unsigned r, int j) -> float {       // one column (edge tiles only)
-            const float x = T[grp_idx(r, j >> 2) + (unsigned)(j & 3)];
-            return (j < 0 || ((cur_mask >> (j & 63)) & 1ull)) ? x : 0.0f;
-        };
+        const unsigned h = (h0 + ch16 * nb15) & 15u;           // of both channels of this lane
+        const int left = NB - (int)(t * (unsigned)kOwnBins);   // bins of the row from this tile's own first on (>= 1)
+        const bool first = t == 0, last = left <= kOwnBins;    // the row's first / last tile: partial sectors possible
+        // instruction i = (u = i & 1: channel ch16 + 16 u, s = i >> 1: sector of the window); element e: window position
+        // 16 s + 4 pcl + e = lane (= row of the tile) 16 + 16 s + 4 pcl + e - h
+        const float* wb = T + (16u + 4u * pcl - h) * kChunk + ch16;
         v4f o[kChunk / 4];
-        if (!sub) {
 #pragma unroll
-            for (int s4 = 0; s4 < kChunk / 4; ++s4) {
-                const unsigned r = s4 * 4 + row0;
-                const int g = (int)L - (int)(((h0 + r * nb15) & 15u) >> 2);
-                o[s4] = *reinterpret_cast<const v4f*>(T + grp_idx(r, g));
-            }
-        } else {
-            // window element e = column 4 (L - a) + e - b: from group L - a (e >= b) or the one before it
-#pragma unroll
-            for (int q2 = 0; q2 < kChunk / 4; q2 += 2) {
-                v4f X[2], Y[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const unsigned r = (q2 + i) * 4 + row0;
-                    const int g = (int)L - (int)(((h0 + r * nb15) & 15u) >> 2);
-                    X[i] = *reinterpret_cast<const v4f*>(T + grp_idx(r, g));
-                    Y[i] = *reinterpret_cast<const v4f*>(T + grp_idx(r, g - 1));
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const unsigned r = (q2 + i) * 4 + row0;
-                    const unsigned h = (h0 + r * nb15) & 15u;
-                    const int g = (int)L - (int)(h >> 2);
-                    const unsigned bsh = h & 3u;
-                    const v4f x = masked(X[i], g), y = masked(Y[i], g - 1);
-                    // z[4 + e - b] of z = {y, x}
-                    const float z1 = y.y, z2 = y.z, z3 = y.w, z4 = x.x, z5 = x.y, z6 = x.z;
-                    o[q2 + i] = bsh == 0 ? x
-                              : bsh == 1 ? v4f{z3, z4, z5, z6}
-                              : bsh == 2 ? v4f{z2, z3, z4, z5}
-                                         : v4f{z1, z2, z3, z4};
-                }
-            }
+        for (int i = 0; i < kChunk / 4; ++i) {
+            const float* wp = wb + (i & 1) * 16 + (i >> 1) * 16 * kChunk;
+            o[i] = v4f{wp[0], wp[kChunk], wp[2 * kChunk], wp[3 * kChunk]};
         }
-        // the groups to carry: lane = (row, 12 + lane / 32) and the group two further on
-        const unsigned cr = lane & 31u;
-        const int cg = 12 + (int)(lane >> 5);
-        v4f c0 = *reinterpret_cast<const v4f*>(T + grp_idx(cr, cg));
-        v4f c1 = *reinterpret_cast<const v4f*>(T + grp_idx(cr, cg + 2));
-        // the <= 3 floats in front of / behind the whole 16-byte pieces of a row's valid positions (edge tiles
-        // only): lane = (row, i), two passes -> fix[0..1] head, fix[2..3] tail
+        // the <= 3 floats in front of / behind the whole 16-byte pieces of a row's valid positions (the row's first
+        // and last tile only): lane = (row, i), two passes -> fix[0..1] head, fix[2..3] tail
         float fix[4] = {0.f, 0.f, 0.f, 0.f};
         const unsigned fr = lane & 31u, fi = lane >> 5;
         const unsigned fh = (h0 + fr * nb15) & 15u;
-        const int pl = carry_ok ? 0 : (int)fh;                       // first valid position of row fr
-        const int ph = min(kTileBins, left + (int)fh);               // one past its last
-        if (!interior && sub) {
+        const int pl = first ? (int)fh : 0;                          // first valid position of row fr
+        const int ph = last ? left + (int)fh : kOwnBins;             // one past its last (<= 63)
+        auto win_at = [&](unsigned rr, int pos, unsigned hrow) -> float {   // one window position, masked
+            const unsigned ln = (unsigned)(pos - (int)hrow + 16);            // the lane that gathered it (< 64 where valid)
+            const float x = T[ln * kChunk + rr];
+            return ((cur_mask >> (ln & 63u)) & 1ull) ? x : 0.0f;
+        };
+        if (first || last) {
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
                 const int pa = pl + (int)fi + 2 * ps, pb = (ph & ~3) + (int)fi + 2 * ps;
-                if (pa < ((pl + 3) & ~3) && pa < ph) fix[ps] = tile_at(fr, pa - (int)fh);
-                if (pb < ph && pb >= pl && (ph & ~3) >= ((pl + 3) & ~3)) fix[2 + ps] = tile_at(fr, pb - (int)fh);
+                if (pa < ((pl + 3) & ~3) && pa < ph) fix[ps] = win_at(fr, pa, fh);
+                if (pb < ph && pb >= pl && (ph & ~3) >= ((pl + 3) & ~3)) fix[2 + ps] = win_at(fr, pb, fh);
             }
         }
         wg_lds_barrier();  // T has been read: the gatherer may blend the next tile into it
-        if (!sub) {
-#pragma unroll
-            for (int s4 = 0; s4 < kChunk / 4; ++s4) {
-                const unsigned r = s4 * 4 + row0;
-                o[s4] = masked(o[s4], (int)L - (int)(((h0 + r * nb15) & 15u) >> 2));
-            }
-        }
-        // (one wave, LDS operations in program order: every read of the old carried groups precedes these writes)
-        *reinterpret_cast<v4f*>(Cy + cr * 16u + (unsigned)(cg - 12) * 4u) = masked(c0, cg);
-        *reinterpret_cast<v4f*>(Cy + cr * 16u + (unsigned)(cg - 10) * 4u) = masked(c1, cg + 2);
         const bool live = !(dbg & 1) && !skip;
         float* obase = out + ((size_t)n * C + k * kChunk) * NB;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, chans_here * (unsigned)NB * 4u);
+        const int rl = first ? (int)h : 0, rh = last ? left + (int)h : kOwnBins;
+        const unsigned msh = 16u + 4u * pcl - h;                // the lane that gathered this lane's first element of sector 0
 #pragma unroll
-        for (int s4 = 0; s4 < kChunk / 4; ++s4) {
-            const unsigned r = s4 * 4 + row0;
-            const unsigned h = (h0 + r * nb15) & 15u;
-            const int p0 = (int)(4 * L);
-            const int rl = carry_ok ? 0 : (int)h, rh = min(kTileBins, left + (int)h);
-            const bool whole = interior || (p0 >= rl && p0 + 4 <= rh);
+        for (int i = 0; i < kChunk / 4; ++i) {
+            const unsigned r = ch16 + 16u * (i & 1);
+            const int p0 = 16 * (i >> 1) + 4 * (int)pcl;
+            // bins in no group (masked by pw > roi_pooled_width, or outside the row) are zero
+            const unsigned nib = (unsigned)((cur_mask >> (16 * (i >> 1))) >> msh);
+            const v4f v = {(nib & 1u) ? o[i].x : 0.f, (nib & 2u) ? o[i].y : 0.f, (nib & 4u) ? o[i].z : 0.f,
+                           (nib & 8u) ? o[i].w : 0.f};
+            const bool whole = p0 >= rl && p0 + 4 <= rh;
             // float offset of position p0 within the (roi, chunk) block; never negative where `whole`
-            const unsigned off = (r * (unsigned)NB + t * kTileBins + (unsigned)p0 - h) * 4u;
+            const unsigned off = (r * (unsigned)NB + t * (unsigned)kOwnBins + (unsigned)p0 - h) * 4u;
             const unsigned o_off = (live && whole && r < chans_here) ? off : kOOB;
-            if (s4 < kMinorStores) buf_store<kMinorAux>(ws, o_off, o[s4]);
-            else buf_store<kStoreAux>(ws, o_off, o[s4]);
+            if (i < kMinorStores) buf_store<kMinorAux>(ws, o_off, v);
+            else buf_store<kStoreAux>(ws, o_off, v);
         }
-        if (!interior && sub) {
+        if (first || last) {
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
                 const int pa = pl + (int)fi + 2 * ps, pb = (ph & ~3) + (int)fi + 2 * ps;
                 const bool oka = live && fr < chans_here && pa < ((pl + 3) & ~3) && pa < ph;
                 const bool okb = live && fr < chans_here && pb < ph && pb >= pl && (ph & ~3) >= ((pl + 3) & ~3);
-                buf_store1<kStoreAux>(ws, oka ? (fr * (unsigned)NB + t * kTileBins + (unsigned)pa - fh) * 4u : kOOB, fix[ps]);
-                buf_store1<kStoreAux>(ws, okb ? (fr * (unsigned)NB + t * kTileBins + (unsigned)pb - fh) * 4u : kOOB, fix[2 + ps]);
-            }
-        }
-        if (flush && left > kTileBins - 15) {
-            // the columns carried out of the run's (or the row's) last tile: positions [0, h) of the window of tile
-            // t + 1, as far as they are bins.  lane = (row, piece g of 4 floats), g and g + 2
-            const int pend = min((int)fh, left - kTileBins + (int)fh);   // valid positions: p < pend
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                const int p0 = 4 * ((int)fi + 2 * ps);
-                v4f w;
-                w.x = Cy[fr * 16u + ((unsigned)(16 + p0 + 0 - (int)fh) & 15u)];
-                w.y = Cy[fr * 16u + ((unsigned)(16 + p0 + 1 - (int)fh) & 15u)];
-                w.z = Cy[fr * 16u + ((unsigned)(16 + p0 + 2 - (int)fh) & 15u)];
-                w.w = Cy[fr * 16u + ((unsigned)(16 + p0 + 3 - (int)fh) & 15u)];
-                const unsigned off = (fr * (unsigned)NB + (t + 1) * kTileBins + (unsigned)p0 - fh) * 4u;
-                const bool okr = live && fr < chans_here;
-                buf_store<kStoreAux>(ws, (okr && p0 + 4 <= pend) ? off : kOOB, w);
-                // the piece that holds the end of the valid positions goes out float by float
-                const bool part = okr && p0 < pend && p0 + 4 > pend;
-                if (sub) {
-                    buf_store1<kStoreAux>(ws, (part && p0 + 0 < pend) ? off + 0u : kOOB, w.x);
-                    buf_store1<kStoreAux>(ws, (part && p0 + 1 < pend) ? off + 4u : kOOB, w.y);
-                    buf_store1<kStoreAux>(ws, (part && p0 + 2 < pend) ? off + 8u : kOOB, w.z);
-                }
+                buf_store1<kStoreAux>(ws, oka ? (fr * (unsigned)NB + t * (unsigned)kOwnBins + (unsigned)pa - fh) * 4u : kOOB, fix[ps]);
+                buf_store1<kStoreAux>(ws, okb ? (fr * (unsigned)NB + t * (unsigned)kOwnBins + (unsigned)pb - fh) * 4u : kOOB, fix[2 + ps]);
             }
         }
     };
@@ -696,37 +657,11 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     //                      first loads of item i | barrier 2: T has been read | phase B -> T
     //   storer:            barrier 1 | tile i-1: T -> registers | barrier 2 | its eight 1 KiB stores, never
     //                      waited for | geometry of item i+1 -> record set p^1
-    // Items of this workgroup: every nslots-th one -- or (SHIFT) RUNS of consecutive tiles of one (roi, chunk) block:
-    // a block is cut into `parts` runs of `len` tiles (parts = dbg >> 8, chosen by the host for an even load), run
-    // rho = roi * parts + part, and the workgroup takes the runs slot, slot + nslots, ...  Both waves walk the same
-    // sequence with next(); kEnd ends it.
+    // Items of this workgroup: every nslots-th one (SHIFT: a row has ceil(NB / 48) tiles -- the host passes that as
+    // ntiles).  Both waves walk the same sequence with next(); kEnd ends it.
     constexpr unsigned kEnd = 0xffffffffu;
-    const unsigned parts = SHIFT ? max(1u, (unsigned)dbg >> 8) : 1u;
-    const unsigned len = (ntiles + parts - 1u) / parts;
-    unsigned run = slot, run_end = 0;   // SHIFT: the current run and one past its last item
-    // dbg & 64: a run that starts inside a block begins one tile EARLY with a "pre" item -- only that tile's last 16
-    // columns are sampled and nothing of it is stored: it fills the carried groups, so that the run's first window
-    // starts on a whole sector like every other and the run before it has nothing to flush (no partial sectors at cuts)
-    const bool pre_tiles = SHIFT && (dbg & 64);
-    bool cur_pre = false;
-    auto enter_run = [&]() -> unsigned {   // first item of run `run` (kEnd beyond the last run); empty parts are skipped
-        for (;; run += nslots) {
-            if (run >= (unsigned)num_rois * parts) return kEnd;
-            const unsigned rn = run / parts, part = run - rn * parts;
-            if (part * len >= (unsigned)ntiles) continue;
-            run_end = rn * (unsigned)ntiles + min((unsigned)ntiles, (part + 1u) * len);
-            cur_pre = pre_tiles && part > 0u;
-            return rn * (unsigned)ntiles + part * len - (cur_pre ? 1u : 0u);
-        }
-    };
-    auto next = [&](unsigned c) -> unsigned {
-        if (!SHIFT) return c + nslots < items ? c + nslots : kEnd;
-        cur_pre = false;
-        if (c + 1u < run_end) return c + 1u;
-        run += nslots;
-        return enter_run();
-    };
-    unsigned cur = SHIFT ? enter_run() : (slot < items ? slot : kEnd);
+    auto next = [&](unsigned c) -> unsigned { return c + nslots < items ? c + nslots : kEnd; };
+    unsigned cur = slot < items ? slot : kEnd;
     if (cur == kEnd) return;
     if (storer) {
         RROI_TRACE(0);
@@ -748,8 +683,6 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         // dbg & 32 (the reference-ABI launcher): the crops of ROIs whose image index is >= batch_size have been
         // written by the prologue launch -- they are not zero-filled here
         bool skip_cur = false, skip_prev = false;
-        bool carry_prev = false;   // SHIFT: the tile before `prev` was its left neighbour, stored by this workgroup
-        bool pre_prev = false;     // SHIFT: `prev` is a pre item (sampled for its last columns, not stored)
 #ifdef RROI_EXPLORE
         bool first_plan = true;
 #endif
@@ -759,14 +692,13 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
 #ifdef RROI_EXPLORE
             // ablation (dbg & 256): the workgroup's FIRST item costs nothing -- no geometry, no taps (its tile is zeros):
             // an upper bound on what any shortening of the launch's start-up chain can gain
-            geometry(A, pt, pp, gl, gh, m, (!SHIFT && (dbg & 256) && first_plan) ? 64u : cur_pre ? 48u : 0u);   // (SHIFT: bits 8.. are the runs per block)
+            geometry(A, pt, pp, gl, gh, m, ((dbg & 256) && first_plan) ? 64u : 0u);
             first_plan = false;
 #else
-            geometry(A, pt, pp, gl, gh, m, cur_pre ? 48u : 0u);
+            geometry(A, pt, pp, gl, gh, m);
 #endif
             if (lane == 0) shead[pp] = make_uint4(gl, gh, (unsigned)m, (unsigned)(m >> 32));
         };
-        bool pre_cur = cur_pre;
 #ifdef RROI_EXPLORE
         bool traced_first = false;
 #endif
@@ -774,17 +706,9 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         for (bool have_prev = false;; have_prev = true) {
             wg_lds_barrier();  // 1: records of item `cur` are in set p; the tile of the previous item is in T
             if (have_prev) {
-                if (SHIFT) {
-                    // the run ends with `prev` (runs do not cross into the next roi's block)
-                    const bool row_end = t_prev + 1u == (unsigned)ntiles;
-                    const bool last = cur != n_prev * (unsigned)ntiles + t_prev + 1u || row_end;
-                    // with pre items the run that follows writes the sector the two runs share
-                    drain_shift(n_prev, t_prev, mask_prev, skip_prev || pre_prev, carry_prev && !pre_prev,
-                                pre_tiles ? row_end : last);
-                    carry_prev = !last;
-                } else {
-                    drain_tile(n_prev, t_prev, mask_prev, skip_prev);  // T -> registers | barrier 2 | stores
-                }
+                // T -> registers | barrier 2 | stores
+                if (SHIFT) drain_shift(n_prev, t_prev, mask_prev, skip_prev);
+                else drain_tile(n_prev, t_prev, mask_prev, skip_prev);
 #ifdef RROI_EXPLORE
                 if (!traced_first) { RROI_TRACE(2); traced_first = true; }
                 if (++drained == 5) RROI_TRACE(6);
@@ -798,9 +722,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             t_prev = t;
             mask_prev = mask_cur;
             skip_prev = skip_cur;
-            pre_prev = pre_cur;
             cur = next(cur);
-            pre_cur = cur_pre;
             if (cur != kEnd) {
                 n = fdiv(cur, div_tiles);
                 t = cur - n * (unsigned)ntiles;
@@ -841,7 +763,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         fetch_lo(p, kEarly, 0);
         issue_lo(rs, 0);
 #ifdef RROI_EXPLORE
-        if (cur == (SHIFT ? cur : slot)) RROI_TRACE(1);
+        if (cur == slot) RROI_TRACE(1);
 #endif
         wg_lds_barrier();  // 2: the storer holds the previous tile in registers: T is free
 

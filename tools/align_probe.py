@@ -48,15 +48,6 @@ if os.environ.get("RROI_ALIGN_PMC"):   # a few launches of four cases for a coun
         return 0.0
     case(64, 11, 96); case(64, 11, 100); case(256, 11, 96); case(256, 11, 100)
     sys.exit(0)
-if os.environ.get("RROI_ALIGN_PARTS"):   # runs per (roi, chunk) block, forced, by ROI count (the host's rule: 0)
-    for ln in (0, 1, 2, 3, 4, 5, 6, 9, 256, 258, 261):
-        lib.rroi_align_debug_set_fwd_shift(-1, -1, ln)
-        print("runs per block", (ln & 255) or "chosen by the library", "(no pre items)" if ln & 256 else "")
-        for ph, pw in ((11, 83), (11, 100)):
-            for Rn in (8, 32, 128, 512, 2048):
-                case(64, ph, pw, R=Rn)
-            case(256, ph, pw, R=32); case(256, ph, pw, R=128); case(256, ph, pw, R=512)
-    sys.exit(0)
 print("shift 1 = what the library does (SHIFT kernels where they pay), 0 = strided items only, 2 = SHIFT forced")
 for C in (64, 256):
     for ph, pw in ((11, 96), (11, 100), (11, 104), (8, 62), (11, 83), (11, 85), (7, 50), (3, 21)):

@@ -169,6 +169,35 @@ __global__ __launch_bounds__(64) void k_store_mix(float* __restrict__ out, int n
     }
 }
 
+// ---- store shapes (round 4): the same bytes -- every (roi, chunk) block of 32 rows x 512 floats -- written in tiles of
+// 64 floats per row with different PER-INSTRUCTION shapes and alignments (policy: 1 of 8 write-through, the rest nt):
+//   SHAPE 0  4 rows x 256 B per instruction (the strided kernel), SHAPE 1  16 rows x 64 B (round 4's first SHIFT
+//   mapping), SHAPE 2  8 rows x 128 B;   `skew` floats are added to every row's start: 0 = rows on 128-byte lines,
+//   16 = on 64-byte sectors only, 4 = on 16-byte pieces only.  The buffer is allocated with room for the skew.
+template <int SHAPE>
+__global__ __launch_bounds__(64) void k_store_shape(float* __restrict__ out, int nchunks, int ntiles, unsigned skew)
+{
+    const unsigned lane = threadIdx.x;
+    const unsigned k = blockIdx.x % nchunks, slot = blockIdx.x / nchunks, nslots = gridDim.x / nchunks;
+    const unsigned items = R * ntiles;
+    const v4u v = {1u, 2u, 3u, lane};
+    for (unsigned item = slot; item < items; item += nslots) {
+        const unsigned n = item / ntiles, t = item % ntiles;
+        float* obase = out + ((size_t)n * C + k * 32) * NB;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, 32u * NB * 4u + 256u);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            unsigned row, col;
+            if (SHAPE == 0) { row = s * 4 + (lane >> 4); col = (lane & 15) * 4; }
+            else if (SHAPE == 1) { row = (lane & 15) + 16 * (s & 1); col = (s >> 1) * 16 + (lane >> 4) * 4; }
+            else { row = (lane & 7) + 8 * (s & 3); col = (s >> 2) * 32 + (lane >> 3) * 4; }
+            const unsigned off = (row * NB + t * 64 + col + skew) * 4u;
+            if (s < 1) __builtin_amdgcn_raw_buffer_store_b128(v, ws, off, 0, 17);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, ws, off, 0, 2);
+        }
+    }
+}
+
 // ---- TA instruction rate: buffer_load_dwordx4 in a 16 KiB (L1-resident) window; a fraction of
 // the 8-lane groups is out of range (MODE 0: none, 1: half, 2: 7/8, 3: all) or exec-masked
 // (MODE 4: half masked by a branch). 8 independent loads in flight.
@@ -306,7 +335,7 @@ int main(int argc, char** argv)
     void* ws;
     const size_t wsb = rroi_align_forward_workspace_bytes(1, C, H, W, R, 0) + (8u << 20);
     CK(hipMalloc(&feat, (size_t)C * H * W * 4));
-    CK(hipMalloc(&out, out_elems * 4));
+    CK(hipMalloc(&out, out_elems * 4 + 4096));   // (+ room for the skewed rows of `kbench shape`)
     CK(hipMalloc(&rois_d, R * 24));
     CK(hipMalloc(&ws, wsb));
     CK(hipMalloc(&sink, 1 << 22));
@@ -394,6 +423,20 @@ int main(int argc, char** argv)
                 fflush(stdout);
             }
         }
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "shape") {
+        // what the write path makes of a tile's stores by the shape of one wave instruction and the rows' alignment
+        for (int rep = 0; rep < 2; ++rep)
+            for (unsigned skew : {0u, 16u, 4u, 1u}) {
+                char nm[96];
+                snprintf(nm, 96, "4 rows x 256 B per instruction, rows + %u floats", skew);
+                report(nm, T.us([&] { hipLaunchKernelGGL(k_store_shape<0>, dim3(3072), dim3(64), 0, 0, out, 8, 8, skew); }, 100), MB);
+                snprintf(nm, 96, "16 rows x 64 B per instruction, rows + %u floats", skew);
+                report(nm, T.us([&] { hipLaunchKernelGGL(k_store_shape<1>, dim3(3072), dim3(64), 0, 0, out, 8, 8, skew); }, 100), MB);
+                snprintf(nm, 96, "8 rows x 128 B per instruction, rows + %u floats", skew);
+                report(nm, T.us([&] { hipLaunchKernelGGL(k_store_shape<2>, dim3(3072), dim3(64), 0, 0, out, 8, 8, skew); }, 100), MB);
+            }
         return 0;
     }
     if (argc > 1 && std::string(argv[1]) == "wceil") {

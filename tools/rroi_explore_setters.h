@@ -18,14 +18,13 @@ int rroi_align_debug_set_split_wgs_per_cu(int v)
     if (v > 0) g_tune.split_wgs_per_cu = v;
     return old;
 }
-// v: 0 never / 1 where it pays / 2 always the SHIFT forms; wgs_per_cu, parts: 0 = the host's rule; parts + 256: no pre items
-int rroi_align_debug_set_fwd_shift(int v, int wgs_per_cu, int parts)
+// v: 0 never / 1 where it pays / 2 always the SHIFT form; wgs_per_cu: 0 = the host's rule (the third argument, round 3's
+// runs per block, is ignored since the tiles overlap: round 4)
+int rroi_align_debug_set_fwd_shift(int v, int wgs_per_cu, int)
 {
     const int old = g_tune.fwd_shift;
     if (v >= 0) g_tune.fwd_shift = v;
     if (wgs_per_cu >= 0) g_tune.shift_wgs_per_cu = wgs_per_cu;
-    if (parts >= 0) g_tune.shift_parts = parts & 255;
-    if (parts >= 0) g_tune.shift_pre = (parts & 256) ? 0 : 1;
     return old;
 }
 // per-workgroup time stamps of rroi_fwd_split_kernel (tools/wg_trace.py): a device buffer of 8 words per workgroup, or NULL
