@@ -81,7 +81,7 @@ int num_cus()
 // rroi_align_debug_set_* setters of tools/rroi_explore_setters.h -- none of that is in the product library.
 struct Tuning {
     int row_pad = -1;             // chunk-major row pitch: -1 = W | 1 (see row_pitch)
-    int waves_per_cu = 12;        // one-wave tiled kernels (the backward's atomic scatter): 12.4 KB of LDS each
+    int waves_per_cu = 12;        // the backward's one-wave atomic scatter (rroi_bwd_tiled_kernel): 12.4 KB of LDS each
     // rroi_fwd_split_kernel: 62-64 VGPRs under __launch_bounds__(128, 6) and 12.1 KB of LDS (10 granules of 1280 B)
     // -> 12 workgroups per CU; a larger grid would run its surplus as a second round
     int split_wgs_per_cu = 12;
@@ -129,8 +129,7 @@ bool shape_ok(int batch_size, int num_rois, int height, int width, int channels,
     return true;
 }
 
-// grid for the tiled kernels: `per_cu` workgroups per CU (default: the one-wave kernels' 12 -- what their 12.4 KB of
-// LDS admits; LDS is granted in 1280-byte granules, and a grid larger than the resident set would run its surplus
+// grid for the tiled kernels: `per_cu` workgroups per CU (default: the 12 that 12.4 KB of LDS per workgroup admit; LDS is granted in 1280-byte granules, and a grid larger than the resident set would run its surplus
 // blocks as a second, mostly empty round) and a multiple of lcm(nchunks, 8) so that blockIdx % nchunks is also
 // stable per XCD.
 int tiled_grid(long items, int nchunks, int per_cu = 0)

@@ -36,7 +36,7 @@ __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float*
     // pixel index of rows 8m..8m+7 is XORed with 4m so that the transposed ds_read_b32 of
     // phase 2 (8 channel quads x 4 pixels per 32-lane group) hits 32 different banks.
     const int tid = threadIdx.x;
-    const size_t zp_index = (size_t)(HW / width) * pitch;  // pixel index of the zero pixel
+    const size_t zp_index = (size_t)(HW / width) * pitch;  // pixel index of the slice's spare last pixel
     const size_t slice_stride = (zp_index + 1) * kChunk;
     const int lane = tid & 63, w = tid >> 6;
     // phase 1 mapping: lane -> 4 consecutive pixels (x4) of channel row (csub); a wave
@@ -260,10 +260,10 @@ __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois,
 // here no wave does both.
 // Template parameters: VEC_STORE 16-byte stores (PH * PW % 4 == 0) | EARLY LO groups issued before barrier 2 | OCC
 // waves per SIMD (__launch_bounds__) | HID HI groups double-buffered unrolled (2) or rolled (3) | ONHWC channels-last
-// crops | SHIFT crops whose rows are not whole 64-byte sectors: runs of tiles and sector-aligned store windows (1:
-// every row a multiple of 16 bytes into its sector, 2: any offset; see drain_shift).  dbg: bit 0 drops the stores, bit 1
-// the tap loads (ablations), bit 5 the reference-ABI launcher's mode, bit 6 SHIFT's pre items, bits 8.. SHIFT's runs
-// per (roi, chunk) block.  Shipped instantiations: the switch in forward_impl (rroi_align_hip.hip).
+// crops | SHIFT crops whose rows are not whole 64-byte sectors: overlapped tiles and sector-aligned store windows,
+// any row offset (see drain_shift).  dbg: bit 0 drops the stores, bit 1
+// the tap loads (ablations), bit 5 the reference-ABI launcher's mode, bit 8 (exploration build) the free first item.
+// Shipped instantiations: the switch in forward_impl (rroi_align_hip.hip).
 // ------------------------------------------------------------------------------------
 constexpr int kStoreAux = 2;      // output stores stream (nt) ...
 constexpr int kMinorStores = 1;   // ... except this many of a tile's eight, which go out write-through (kMinorAux)
@@ -300,18 +300,15 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // two classes, each padded to a multiple of 8: ceil(a/8) + ceil(b/8) <= 9 for a + b <= 64 (and one
     // forced LO group + 8 HI groups when a = 0)
     constexpr int kMaxGroups = kIters + 1;
-    // LO groups whose loads are issued ahead of the previous tile's stores.  A/B in one process (tools/kbench
-    // early, three rounds): 1 group 46.1-47.2 us kernel / 53.85 us step, 2 groups 45.45 / 53.45, 3 45.7 / 53.65,
-    // 4 46.4 / 53.9, 5 47.3 / 54.75
+    // LO groups whose loads are issued before barrier 2, besides the first one (0 in the NCHW forms: no difference
+    // measured with the loads in a wave of their own; 2 in the channels-last form, round 3's first shape)
     constexpr int kEarly = EARLY;
     constexpr unsigned kPadPos = kTileBins;  // "bin position" of a padding record
     // T: rows 0..31 are the tile; the tail absorbs the writes of padding records (4 rows at the
     // tile's pitch, 32 columns: 32 different banks).  LDS is granted in 1280-byte granules on gfx950;
     // the block (T 9648 + records 2448 = 12096 B) stays within the 10 granules that 12 waves per CU
-    // allow.  Round 2 also tried a block of 11152 B (padding writes into the four spare columns of the
-    // tile pitch), which admits 14 waves per CU: 12 waves 47.2 us, 13 48.0, 14 48.5 (tools/kbench abl)
-    // -- the kernel is bound by the write path, not by latency -- and the spare-column writes are
-    // 4-way bank-conflicted (SQ_LDS_BANK_CONFLICT 40 % instead of 32 % of the LDS cycles): not kept.
+    // allow (a smaller block that admits 14 was measured in round 2 and is no faster: the kernel is bound by the
+    // write path, not by latency; profiles/NOTEBOOK.md 5.2).
     // SHIFT: the tile is BIN-MAJOR instead -- T[lane's bin * 32 + channel], 64 gathered bins of which the LAST 48 are the
     // tile's own (the first 16 are the tile before's last: every item is self-contained, see drain_shift); row 64 takes
     // the padding records, rows 65..79 are never written (a window position beyond the gathered bins reads them and
@@ -650,8 +647,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
 
     // The two waves walk the same items.  gfx950 counts loads and stores with ONE in-order counter, so in
     // a wave that does both a load issued after a tile's stores cannot be consumed before those stores are
-    // acknowledged (microseconds, with 256 MiB streaming out) -- rroi_fwd_tiled_kernel orders its phases
-    // around that.  Here no wave does both: the gatherer's vmcnt only ever sees loads, the storer's only
+    // acknowledged (microseconds, with 256 MiB streaming out).  Here no wave does both: the gatherer's vmcnt only ever sees loads, the storer's only
     // stores, and they meet at two s_barriers per tile (which do not drain vmcnt):
     //   gatherer, item i:  barrier 1: the records of item i are in set p, tile i-1 is complete in T |
     //                      first loads of item i | barrier 2: T has been read | phase B -> T

@@ -81,7 +81,7 @@ def test_workspace_query_is_host_only():
     from rroi_align._ext import rroi_align as ext
     n = ext._lib.rroi_align_forward_workspace_bytes(1, 256, 160, 160, 512, ext.LAYOUT_NCHW)
     assert n >= 256 * 160 * 160 * 4 + 512 * 32
-    assert n < 1.02 * (256 * 160 * 160 * 4) + 512 * 32 + 4096  # padded row pitch + zero pixels
+    assert n < 1.02 * (256 * 160 * 160 * 4) + 512 * 32 + 4096  # padded row pitch + a spare pixel per slice
     # channels_last with C % 4 == 0 is consumed in place: only the affine table
     assert ext._lib.rroi_align_forward_workspace_bytes(1, 256, 160, 160, 512, ext.LAYOUT_NHWC) < 32768
     assert ext._lib.rroi_align_forward_workspace_bytes(0, 256, 160, 160, 512, 0) == 0

@@ -219,9 +219,9 @@ def test_backward_many_rois_on_one_pixel(ext, oracle):
                                          (260, 96, 11, 85, 3), (2100, 32, 3, 21, 1)])
 def test_forward_rows_that_are_not_whole_sectors(ext, oracle, R, C, ph, pw, B):
     """Crops whose rows are not multiples of 64 bytes (PH * PW % 16 != 0), with enough ROIs for the
-    tiled path's SHIFT kernels (runs of tiles per workgroup, sector-aligned store windows, columns
-    carried from tile to tile): bit-exact like every other shape, also into a buffer that starts 4
-    bytes off a 16-byte boundary, and nothing written outside the crops."""
+    tiled path's SHIFT form (sector-aligned store windows over overlapped tiles): bit-exact like
+    every other shape, also into a buffer that starts 4 bytes off a 16-byte boundary, and nothing written outside
+    the crops."""
     f, r = Wk.bench_inputs(R=R, C=C, H=60, W=90, img=360, seed=R + pw, batch=B)
     r[7, 3] = 0.0               # a degenerate ROI
     ro = r.copy()

@@ -174,6 +174,34 @@ __global__ __launch_bounds__(64) void k_store_mix(float* __restrict__ out, int n
 //   SHAPE 0  4 rows x 256 B per instruction (the strided kernel), SHAPE 1  16 rows x 64 B (round 4's first SHIFT
 //   mapping), SHAPE 2  8 rows x 128 B;   `skew` floats are added to every row's start: 0 = rows on 128-byte lines,
 //   16 = on 64-byte sectors only, 4 = on 16-byte pieces only.  The buffer is allocated with room for the skew.
+// the SHIFT form's own pattern: tiles of 48 floats per row (three sectors), 16 rows x 64 B per instruction, six
+// instructions per tile; rows of NBX floats (NBX % 16 != 0 gives every row its own phase h, windows start at -h)
+template <int NBX, int WIN = 48>
+__global__ __launch_bounds__(64) void k_store_win48(float* __restrict__ out, int nchunks, unsigned rois)
+{
+    const unsigned lane = threadIdx.x, ch16 = lane & 15u, pcl = lane >> 4;
+    const unsigned k = blockIdx.x % nchunks, slot = blockIdx.x / nchunks, nslots = gridDim.x / nchunks;
+    constexpr unsigned ntiles = (NBX + WIN - 1) / WIN;
+    const unsigned items = rois * ntiles;
+    const v4u v = {1u, 2u, 3u, lane};
+    for (unsigned item = slot; item < items; item += nslots) {
+        const unsigned n = item / ntiles, t = item % ntiles;
+        const size_t blk = ((size_t)n * 256 + k * 32) * NBX;
+        float* obase = out + blk;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, 32u * NBX * 4u);
+        const unsigned h = (unsigned)((blk + (size_t)ch16 * NBX) & 15u);
+#pragma unroll
+        for (int i = 0; i < WIN / 8; ++i) {
+            const unsigned r = ch16 + 16u * (i & 1), p0 = 16u * (i >> 1) + 4u * pcl;
+            const int j = (int)(t * WIN + p0) - (int)h;
+            const bool ok = j >= 0 && j + 4 <= NBX;
+            const unsigned off = ok ? (r * NBX + (unsigned)j) * 4u : 0x80000000u;
+            if (i < 1) __builtin_amdgcn_raw_buffer_store_b128(v, ws, off, 0, 17);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, ws, off, 0, 2);
+        }
+    }
+}
+
 template <int SHAPE>
 __global__ __launch_bounds__(64) void k_store_shape(float* __restrict__ out, int nchunks, int ntiles, unsigned skew)
 {
@@ -422,6 +450,20 @@ int main(int argc, char** argv)
                        lines, a, atom / a / 1e3, atom / 64 * lines / a / 1e3, b, atom / b / 1e3, atom / 64 * lines / b / 1e3, c, d);
                 fflush(stdout);
             }
+        }
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "win48") {
+        // store-only ceiling of the SHIFT form's windows (48 floats per tile and row, sector-aligned), by row length
+        for (int rep = 0; rep < 2; ++rep) {
+            report("48-float windows, rows of 1100 floats (11 x 100), 238 ROIs", T.us([&] { hipLaunchKernelGGL(k_store_win48<1100>, dim3(3072), dim3(64), 0, 0, out, 8, 238u); }, 100), 238.0 * 256 * 1100 * 4 / 1e6);
+            report("48-float windows, rows of 913 floats (11 x 83), 287 ROIs", T.us([&] { hipLaunchKernelGGL(k_store_win48<913>, dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
+            report("48-float windows, rows of 1056 floats (11 x 96), 248 ROIs", T.us([&] { hipLaunchKernelGGL(k_store_win48<1056>, dim3(3072), dim3(64), 0, 0, out, 8, 248u); }, 100), 248.0 * 256 * 1056 * 4 / 1e6);
+            report("64-float windows, rows of 1100 floats, 238 ROIs", T.us([&] { hipLaunchKernelGGL((k_store_win48<1100, 64>), dim3(3072), dim3(64), 0, 0, out, 8, 238u); }, 100), 238.0 * 256 * 1100 * 4 / 1e6);
+            report("64-float windows, rows of 913 floats, 287 ROIs", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 64>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
+            report("32-float windows, rows of 913 floats, 287 ROIs", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 32>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
+            report("128-float windows, rows of 913 floats, 287 ROIs", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 128>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
+            report("112-float windows, rows of 913 floats, 287 ROIs", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 112>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
         }
         return 0;
     }
