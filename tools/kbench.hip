@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) void k_store_mix(float* __restrict__ out, int n
 //   16 = on 64-byte sectors only, 4 = on 16-byte pieces only.  The buffer is allocated with room for the skew.
 // the SHIFT form's own pattern: tiles of 48 floats per row (three sectors), 16 rows x 64 B per instruction, six
 // instructions per tile; rows of NBX floats (NBX % 16 != 0 gives every row its own phase h, windows start at -h)
-template <int NBX, int WIN = 48>
+template <int NBX, int WIN = 48, int ORDER = 0>
 __global__ __launch_bounds__(64) void k_store_win48(float* __restrict__ out, int nchunks, unsigned rois)
 {
     const unsigned lane = threadIdx.x, ch16 = lane & 15u, pcl = lane >> 4;
@@ -192,7 +192,10 @@ __global__ __launch_bounds__(64) void k_store_win48(float* __restrict__ out, int
         const unsigned h = (unsigned)((blk + (size_t)ch16 * NBX) & 15u);
 #pragma unroll
         for (int i = 0; i < WIN / 8; ++i) {
-            const unsigned r = ch16 + 16u * (i & 1), p0 = 16u * (i >> 1) + 4u * pcl;
+            // ORDER 0: the two channel halves alternate (a row's next sector two instructions later); 1: a row's sectors
+            // in consecutive instructions
+            const unsigned uu = ORDER ? i / (WIN / 16) : (i & 1), ss = ORDER ? i % (WIN / 16) : (i >> 1);
+            const unsigned r = ch16 + 16u * uu, p0 = 16u * ss + 4u * pcl;
             const int j = (int)(t * WIN + p0) - (int)h;
             const bool ok = j >= 0 && j + 4 <= NBX;
             const unsigned off = ok ? (r * NBX + (unsigned)j) * 4u : 0x80000000u;
@@ -459,6 +462,9 @@ int main(int argc, char** argv)
             report("48-float windows, rows of 1100 floats (11 x 100), 238 ROIs", T.us([&] { hipLaunchKernelGGL(k_store_win48<1100>, dim3(3072), dim3(64), 0, 0, out, 8, 238u); }, 100), 238.0 * 256 * 1100 * 4 / 1e6);
             report("48-float windows, rows of 913 floats (11 x 83), 287 ROIs", T.us([&] { hipLaunchKernelGGL(k_store_win48<913>, dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
             report("48-float windows, rows of 1056 floats (11 x 96), 248 ROIs", T.us([&] { hipLaunchKernelGGL(k_store_win48<1056>, dim3(3072), dim3(64), 0, 0, out, 8, 248u); }, 100), 248.0 * 256 * 1056 * 4 / 1e6);
+            report("48-float windows, 1100, a row's sectors back to back", T.us([&] { hipLaunchKernelGGL((k_store_win48<1100, 48, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 238u); }, 100), 238.0 * 256 * 1100 * 4 / 1e6);
+            report("48-float windows, 913, a row's sectors back to back", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
+            report("64-float windows, 913, a row's sectors back to back", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 64, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
             report("64-float windows, rows of 1100 floats, 238 ROIs", T.us([&] { hipLaunchKernelGGL((k_store_win48<1100, 64>), dim3(3072), dim3(64), 0, 0, out, 8, 238u); }, 100), 238.0 * 256 * 1100 * 4 / 1e6);
             report("64-float windows, rows of 913 floats, 287 ROIs", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 64>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
             report("32-float windows, rows of 913 floats, 287 ROIs", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 32>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
