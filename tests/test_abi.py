@@ -147,3 +147,25 @@ def test_python_constants_are_the_headers():
         assert getattr(ext, name) == value, name
     assert set(ext.BACKWARD_PATHS) == {v for k, v in defs.items() if k.startswith("PATH_")}
     assert set(ext.FORWARD_PATHS) <= set(ext.BACKWARD_PATHS)
+
+
+@pytest.mark.gpu
+def test_write_probe_and_trig_recipe_hooks():
+    """Round-4 entry points: the bench's write probe fills exactly the floats it is given (values that differ from
+    store to store, nothing behind them), refuses misaligned / odd requests; the trig recipe is per-device state that
+    the setter returns and validates."""
+    import torch
+    from rroi_align._ext import rroi_align as ext
+    buf = torch.full((4096 + 8,), float("nan"), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert ext._lib.rroi_align_write_probe_hip(buf.data_ptr(), 4096, st) == 1
+    h = buf.cpu().numpy()
+    assert np.isfinite(h[:4096]).all() and np.isnan(h[4096:]).all() and len(np.unique(h[:4096:4])) > 900
+    assert ext._lib.rroi_align_write_probe_hip(buf.data_ptr(), 4094, st) == 0       # not a multiple of 4 floats
+    assert ext._lib.rroi_align_write_probe_hip(buf.data_ptr() + 4, 4096, st) == 0   # not 16-byte aligned
+    assert ext._lib.rroi_align_write_probe_hip(buf.data_ptr(), 0, st) == 1
+    assert ext._lib.rroi_align_get_trig_recipe_hip() == ext.TRIG_DOUBLE
+    assert ext._lib.rroi_align_set_trig_recipe_hip(5) == 0 and ext._lib.rroi_align_get_trig_recipe_hip() == ext.TRIG_DOUBLE
+    assert ext.set_trig_recipe(ext.TRIG_FP32) == ext.TRIG_DOUBLE
+    assert ext._lib.rroi_align_get_trig_recipe_hip() == ext.TRIG_FP32
+    assert ext.set_trig_recipe(ext.TRIG_DOUBLE) == ext.TRIG_FP32

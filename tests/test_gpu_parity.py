@@ -664,3 +664,12 @@ def test_reference_launcher_on_rows_that_are_not_whole_sectors(ext):
     assert torch.equal(out, want)
     assert ext.rroi_align_forward_cuda(11, 83, 0.25, F, R, out, ix, iy) == 1
     assert torch.equal(out, want) and not ix.isnan().any() and not iy.isnan().any()
+    # two images: the launcher's signature has no batch count, so the ROIs of image 1 are sampled by the prologue's
+    # extra blocks and SKIPPED by the gather -- also by its SHIFT form, whose windows reach over row ends
+    f2, r2 = Wk.bench_inputs(R=300, C=64, H=60, W=90, img=360, seed=92, batch=2)
+    F2, R2 = dev(f2), dev(r2)
+    want2 = ext.forward(F2, R2, 11, 83, 0.25, path=ext.PATH_TILED)
+    out2 = torch.full((300, 64, 11, 83), float("nan"), device="cuda")
+    assert ext._lib.RROIAlignForwardLaucher(F2.data_ptr(), 0.25, 300, 60, 90, 64, 11, 83, R2.data_ptr(), out2.data_ptr(),
+                                            None, None, st) == 1
+    assert int((r2[:, 0] == 1).sum()) > 50 and torch.equal(out2, want2)

@@ -8,6 +8,8 @@ cosine is not correctly rounded, so over enough angles the two affines differ in
 for some ROIs, and where such a difference meets a rounding tie a bin's sample point moves.
 
     python tools/fuzz_ref.py [rois_per_round] [rounds] [seed]  ->  one JSON line
+    RROI_FUZZ_TRIG=fp32     the product's opt-in recipe (ext.set_trig_recipe(ext.TRIG_FP32)) for the campaign
+    RROI_FUZZ_POOLED=11x83  another pooled size
 
 Per round: `rois_per_round` random ROIs (every angle in [-180, 180), centres on and off the
 half-integer grid, C = 1 so a bin is one output element), pooled 8 x 64 on a 160 x 160 map, through
@@ -58,6 +60,8 @@ def main():
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 11)
     ref = load_ref()
+    trig = os.environ.get("RROI_FUZZ_TRIG", "double")
+    ext.set_trig_recipe({"double": ext.TRIG_DOUBLE, "fp32": ext.TRIG_FP32}[trig])
     ph, pw, s, H, W = 8, 64, 0.25, 160, 160
     if os.environ.get("RROI_FUZZ_POOLED"):   # e.g. 11x83: rows that are not whole sectors (the SHIFT kernels)
         ph, pw = (int(v) for v in os.environ["RROI_FUZZ_POOLED"].split("x"))
@@ -91,6 +95,8 @@ def main():
             worst.append([float(v) for v in r[i]] + [int(dxy[i].sum())])
     tot["differing_bins_per_million"] = round(1e6 * tot["bins_centre_differs"] / max(1, tot["bins"]), 3)
     tot["pooled"] = [ph, pw]
+    tot["trig_recipe"] = trig
+    ext.set_trig_recipe(ext.TRIG_DOUBLE)
     tot["example_rois"] = worst[:8]
     print(json.dumps(tot))
 
