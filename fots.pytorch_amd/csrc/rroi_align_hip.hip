@@ -95,6 +95,7 @@ struct Tuning {
     // leaves no dirty lines for the end of the launch to flush.  Non-temporal LOADS in the gather: +16 us.
     int bwd_relayout_aux = 16;
     int bwd_buckets = 1;          // one-pass pixel lists (round 3); 0: count / scan / fill as in rounds 1-2
+    int bwd_nchw_direct = 1;      // the list gather stores an NCHW bottom_diff itself where that pays (round 4); 0: never
 };
 #ifdef RROI_EXPLORE
 Tuning g_tune;
@@ -917,24 +918,47 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
         // (3) gather: one thread group per key, no grid-stride
         unsigned sub_shift = 3;  // 8 lanes = one chunk
         while ((1u << sub_shift) < 8u * (unsigned)nchunks && sub_shift < 6) ++sub_shift;
+        // NCHW bottom_diff written in place (round 4; tools/bwd_nchw_ab.py, profiles/r04_bwd_nchw_ab.txt): a workgroup
+        // needs whole rows (8 pixels) of a key tile, i.e. at most 32 lanes per pixel -- wider pixels deal their
+        // passes of four chunks to blockIdx.y.  cfg3 128.5 -> 124.1 us, C = 64 / 128 at R = 512 87.9 -> 82.4 / 78.4 ->
+        // 74.5, R = 16...32 35.7 -> 29.3 / 23.8 -> 19.2 (the relayout launch was a fifth of those calls); where the
+        // lists are long (41 bins per map pixel) the workgroup's wait for its slowest pixel costs what the
+        // launch saved (2048 x 256: 577 / 580; 512 x 512 on 80 x 80: 272 / 278): the scratch form stays there.
+        const bool nchw_direct = !bd_nhwc && g_tune.bwd_nchw_direct != 0 &&
+                                 (double)num_rois * NB <= 24.0 * (double)batch_size * HW;
+        unsigned gy = 1;
+        if (nchw_direct && sub_shift == 6) {
+            sub_shift = 5;
+            gy = (unsigned)ceil_div(nchunks, 4);
+        }
         const unsigned groups_per_block = 256u >> sub_shift;
         // whole groups of 8 key tiles (the kernel deals the tiles of a group to the 8 XCDs)
         const long wg_per_tile = 32 / groups_per_block;  // 1, 2, 4 or 8
         const long gblocks = ceil_div(ceil_div((long)KL.keys, 32L), 8L) * 8L * wg_per_tile;
         // the lists: count / scan / fill segments (`off` = scanned offsets) or buckets (`off` = the counters)
         const unsigned* loff = buckets ? reinterpret_cast<const unsigned*>(ws.cnt) : ws.off;
-#define RROI_LAUNCH_G(NHWC, BUCK, DST)                                                                        \
-    hipLaunchKernelGGL((rroi_bwd_gather_kernel<NHWC, BUCK>), dim3((unsigned)gblocks), dim3(256), 0, stream,    \
+#define RROI_LAUNCH_G(DSTK, BUCK, DST)                                                                        \
+    hipLaunchKernelGGL((rroi_bwd_gather_kernel<DSTK, BUCK>), dim3((unsigned)gblocks, gy), dim3(256), 0, stream, \
                        td_nhwc ? top_diff : ws.tdT, loff, ws.bsum, ws.pairs, DST, channels, height, width,    \
                        pitch, nchunks, chunk_stride, line_stride, sub_shift, KL, make_fastdiv(KL.Ht * KL.Wt), \
                        make_fastdiv(KL.Wt), ws.scan_blocks, raw_bsum, BL)
         if (bd_nhwc) {
-            if (buckets) RROI_LAUNCH_G(true, true, bottom_diff);
-            else RROI_LAUNCH_G(true, false, bottom_diff);
+            if (buckets) RROI_LAUNCH_G(kDstNhwc, true, bottom_diff);
+            else RROI_LAUNCH_G(kDstNhwc, false, bottom_diff);
             return launch_status();  // written in place: no relayout back
         }
-        if (buckets) RROI_LAUNCH_G(false, true, ws.gcm);
-        else RROI_LAUNCH_G(false, false, ws.gcm);
+        if (nchw_direct) {
+            if (accumulate) {
+                if (buckets) RROI_LAUNCH_G(kDstNchwAdd, true, bottom_diff);
+                else RROI_LAUNCH_G(kDstNchwAdd, false, bottom_diff);
+            } else {
+                if (buckets) RROI_LAUNCH_G(kDstNchw, true, bottom_diff);
+                else RROI_LAUNCH_G(kDstNchw, false, bottom_diff);
+            }
+            return launch_status();  // written in place
+        }
+        if (buckets) RROI_LAUNCH_G(kDstChunkMajor, true, ws.gcm);
+        else RROI_LAUNCH_G(kDstChunkMajor, false, ws.gcm);
 #undef RROI_LAUNCH_G
         st = launch_status();
         if (st != 1) return st;

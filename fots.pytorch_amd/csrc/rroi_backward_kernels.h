@@ -254,7 +254,14 @@ __global__ __launch_bounds__(1024) void rroi_scan2_kernel(unsigned* __restrict__
 // the (very uneven) list lengths.  The 16-byte loads of eight pairs are in flight together.
 // BUCKET: the lists are the fixed-capacity buckets of the one-pass build (`off` = the per-key counters, `bsum`
 // unused) plus the per-key overflow chains.
-template <bool DST_NHWC, bool BUCKET = false>
+// DST: where the gradient goes.  kDstChunkMajor: the chunk-major scratch (relaid out to NCHW by rroi_cm_to_nchw_kernel);
+// kDstNhwc: the caller's channels-last bottom_diff in place; kDstNchw / kDstNchwAdd (round 4): the caller's NCHW
+// bottom_diff in place (= / +=) -- with sub <= 32 the 256 / sub pixels of a workgroup are whole rows of an 8 x 4 key
+// tile (eight consecutive x), their sums change hands through LDS and leave as whole 32-byte sectors of a map row per
+// channel: the chunk-major round trip (26 MB written, read, written again at cfg3) and its launch are gone.  The
+// host deals the channel passes to blockIdx.y then (a pass = sub / 8 chunks), so that a pixel still takes one round.
+enum GatherDst { kDstChunkMajor = 0, kDstNhwc = 1, kDstNchw = 2, kDstNchwAdd = 3 };
+template <int DST, bool BUCKET = false>
 __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     const float* __restrict__ tdT, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
     const uint2* __restrict__ pairs, float* __restrict__ gcm, int C, int height, int width, int pitch,
@@ -262,30 +269,35 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     FastDiv div_bt, FastDiv div_wt, unsigned scan_blocks, int raw_bsum,
     BucketLists bl = BucketLists{0u, nullptr, nullptr, nullptr})
 {
+    constexpr bool DST_NHWC = DST == kDstNhwc, TO_NCHW = DST >= kDstNchw;
+    constexpr unsigned THREADS = 256u, kLogThreads = 8u;
     __shared__ unsigned bs_lds[kInlineScanBlocks];
+    __shared__ float xpose[TO_NCHW ? THREADS * 4 : 4];
     if (!BUCKET) bsum = block_prefix(bsum, scan_blocks, raw_bsum != 0, bs_lds);  // before any thread leaves
-    // Workgroup -> keys: the G = 2^(sub_shift-3) workgroups that cover one 8 x 4 key tile get
+    // Workgroup -> keys: the G = 2^gshift workgroups that cover one 8 x 4 key tile get
     // block indices that are equal modulo 8, i.e. run on ONE XCD: neighbouring pixels share
     // source lines (the 2 x 2 footprint of a bin), and only an XCD's own L2 can serve them twice.
-    const unsigned gshift = sub_shift - 3u;            // log2(workgroups per key tile)
+    const unsigned gshift = sub_shift + 5u - kLogThreads;   // log2(workgroups per key tile)
     const unsigned bq = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
     const unsigned tile = ((bq >> gshift) << 3) + xcd;  // 8 tiles in flight, one per XCD
     const unsigned wg = (tile << gshift) + (bq & ((1u << gshift) - 1u));
-    const unsigned tid = wg * 256u + threadIdx.x;
+    const unsigned tid = wg * THREADS + threadIdx.x;
     const unsigned sub = 1u << sub_shift;              // lanes per pixel (8..64)
     const unsigned sl = tid & (sub - 1u);              // lane within the pixel's group
     const unsigned key = tid >> sub_shift;
-    if (key >= L.keys) return;
-    // key -> (b, y, x)
-    const unsigned blk = key >> 5, in = key & 31u;
+    // key -> (b, y, x); the padding of the key space has no list (and, TO_NCHW, stays for the barrier)
+    bool live = key < L.keys;
+    const unsigned blk = (live ? key : 0u) >> 5, in = key & 31u;
     const unsigned b = fdiv(blk, div_bt);              // / (Ht*Wt)
     const unsigned r = blk - b * (L.Ht * L.Wt);
     const unsigned by = fdiv(r, div_wt);
     const unsigned y = by * 4u + (in >> 3), x = (r - by * L.Wt) * 8u + (in & 7u);
-    if (y >= (unsigned)height || x >= (unsigned)width) return;  // padding of the key space
-    unsigned beg, end;
+    live = live && y < (unsigned)height && x < (unsigned)width;
+    if (!TO_NCHW && !live) return;
+    unsigned beg = 0u, end = 0u;
     int chain = -1;   // BUCKET: newest overflow entry of this pixel
-    if (BUCKET) {
+    if (!live) {
+    } else if (BUCKET) {
         const unsigned have = off[key];
         beg = key << bl.kshift;
         end = beg + min(have, 1u << bl.kshift);
@@ -302,7 +314,9 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
 #endif
     constexpr int kDepth = RROI_GATHER_DEPTH;
     // channel passes of `sub / 8` chunks each (one pass when C <= 256)
-    for (unsigned k0 = 0; k0 < (unsigned)nchunks; k0 += sub >> 3) {
+    // (gridDim.y > 1: the channel passes are dealt to blockIdx.y instead of run one after the other)
+    const unsigned kstep = gridDim.y * (sub >> 3);
+    for (unsigned k0 = blockIdx.y * (sub >> 3); k0 < (unsigned)nchunks; k0 += kstep) {
         const unsigned k = k0 + (sl >> 3);
         const bool c_ok = k < (unsigned)nchunks && k * kChunk + quad * 4u < (unsigned)C;
         // where the 32 channels of chunk k of list entry `line` live: the relaid-out top_diff
@@ -380,7 +394,37 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
                              !(fabsf(acc.w) <= 3.0e38f);
             if (__ballot(bad)) acc = walk(std::true_type{});   // rare: a gradient that is not finite
         }
-        if (c_ok) {
+        if (TO_NCHW) {
+            // (pixel, 4 channels) per thread in, (channel, 4 consecutive x) per thread out: lanes 2i and 2i + 1 store
+            // the two halves of one 32-byte sector of channel i's map row
+            *reinterpret_cast<v4f*>(xpose + threadIdx.x * 4u) = acc;   // [pixel of the workgroup][channel of the pass]
+            __syncthreads();
+            const unsigned t = threadIdx.x, cp = sub * 4u;             // channels per pass
+            const unsigned c = (t >> 1) & (cp - 1u), row = t >> (sub_shift + 3u), pw0 = row * 8u + (t & 1u) * 4u;
+            const float* tr = xpose + pw0 * cp + c;
+            v4f v = {tr[0], tr[cp], tr[2u * cp], tr[3u * cp]};
+            // the workgroup's first key is the first of a tile row: the block is the same for all its pixels
+            const unsigned key0 = (wg * THREADS) >> sub_shift;
+            const unsigned in0 = (key0 & 31u) + pw0;
+            const unsigned blk0 = (key0 < L.keys ? key0 : 0u) >> 5;
+            const unsigned b0 = fdiv(blk0, div_bt), r0 = blk0 - b0 * (L.Ht * L.Wt), by0 = fdiv(r0, div_wt);
+            const unsigned y0 = by0 * 4u + (in0 >> 3), x0 = (r0 - by0 * L.Wt) * 8u + (in0 & 7u);
+            const unsigned cg = k0 * kChunk + c;
+            if (key0 < L.keys && cg < (unsigned)C && y0 < (unsigned)height && x0 < (unsigned)width) {
+                float* o = gcm + (((size_t)b0 * C + cg) * height + y0) * (size_t)width + x0;
+                if ((width & 3) == 0 && (reinterpret_cast<uintptr_t>(gcm) & 15) == 0) {
+                    v4f* o4 = reinterpret_cast<v4f*>(o);   // x0 % 4 == 0 and W % 4 == 0: inside together
+                    if (DST == kDstNchwAdd) v += *o4;
+                    *o4 = v;
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (x0 + j < (unsigned)width) o[j] = DST == kDstNchwAdd ? o[j] + e[j] : e[j];
+                }
+            }
+            if (k0 + kstep < (unsigned)nchunks) __syncthreads();   // the next pass reuses the tile
+        } else if (c_ok) {
             // chunk-major gradient (relaid out to NCHW afterwards), or the caller's channels-last
             // gradient (B, H, W, C) written directly: `gcm` is then bottom_diff itself
             float* dst = DST_NHWC

@@ -202,6 +202,40 @@ def test_more_than_256_channels(ext, oracle):
         assert np.abs(g - gwant).max() <= BWD_RTOL * max(1.0, float(np.abs(gwant).max())), f"path {p}"
 
 
+def test_backward_gather_writes_nchw_in_place(ext, oracle):
+    """Round 4: with at most 24 bins per map pixel the list gathers store the caller's NCHW gradient themselves
+    (rroi_bwd_gather_kernel<kDstNchw / kDstNchwAdd>): whole 32-byte sectors of a map row per channel out of an LDS
+    tile, no chunk-major scratch, no relayout launch.  Maps whose width is not a multiple of 4 (scalar stores) or
+    of 8 / height of 4 (padded key tiles), channel counts that need several passes over blockIdx.y with a ragged last
+    chunk (C = 300: 10 chunks in groups of 4), two images; every element of a NaN-filled gradient is written; the
+    reference-ABI launcher's accumulating form adds k times the gradient in k calls."""
+    stream = torch.cuda.current_stream().cuda_stream
+    for (R, C, H, W, ph, pw, B) in ((40, 300, 37, 61, 8, 32, 2), (64, 96, 61, 77, 8, 64, 1), (24, 256, 30, 44, 11, 83, 1),
+                                    (64, 20, 33, 50, 8, 64, 1), (32, 130, 40, 56, 8, 64, 3)):
+        f, r = Wk.bench_inputs(R=R, C=C, H=H, W=W, img=4 * W, seed=R + C, batch=B)
+        assert R * ph * pw <= 24 * B * H * W
+        gout = np.random.default_rng(C).standard_normal((R, C, ph, pw)).astype(np.float32)
+        want = oracle.backward_c(gout, r, f.shape, 0.25)
+        scale = max(1.0, float(np.abs(want).max()))
+        G, Rr = dev(gout), dev(r)
+        nb = ext._lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, ph, pw)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        for p in (ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS):
+            got = torch.full(f.shape, float("nan"), device="cuda")
+            assert ext._lib.rroi_align_backward_hip(G.data_ptr(), 0.25, B, R, H, W, C, ph, pw, Rr.data_ptr(),
+                                                    got.data_ptr(), ws.data_ptr(), nb, p, stream) == 1
+            g = got.cpu().numpy()
+            assert np.abs(g - want).max() <= BWD_RTOL * scale, (R, C, H, W, p)      # (NaN left behind fails this too)
+            assert np.array_equal(g == 0, want == 0)
+        if R * C * ph * pw >= 200_000:    # the launcher takes its tiled form (no con_idx read): += on every call
+            gin = torch.zeros(f.shape, device="cuda")
+            dummy = torch.empty(1, device="cuda")
+            for k in (1, 2):
+                assert ext._lib.RROIAlignBackwardLaucher(G.data_ptr(), 0.25, B, R, H, W, C, ph, pw, Rr.data_ptr(),
+                                                         gin.data_ptr(), dummy.data_ptr(), dummy.data_ptr(), stream) == 1
+                assert np.abs(gin.cpu().numpy() - k * want).max() <= 3 * BWD_RTOL * scale, (R, C, k)
+
+
 def test_backward_many_rois_on_one_pixel(ext, oracle):
     """200 identical ROIs: every touched pixel's list holds 200 x its pairs (long lists, the
     counters' hot spots) and untouched pixels must come out exactly zero."""

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Round 4: the backward's list gather storing NCHW itself (rroi_bwd_gather_kernel<kDstNchw>) against the chunk-major
+scratch + rroi_cm_to_nchw_kernel launch, explore build, arms interleaved; outputs compared bit for bit (same sums in
+the same order: only the store differs).   python tools/bwd_nchw_ab.py  ->  one line per shape"""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import workloads as Wk
+lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_explore", "librroi_align_hip_explore.so"))
+vp, fl, it, sz = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
+lib.rroi_align_backward_hip.argtypes = [vp, fl, it, it, it, it, it, it, it, vp, vp, vp, sz, it, vp]
+lib.rroi_align_backward_workspace_bytes.restype = sz
+lib.rroi_align_backward_workspace_bytes.argtypes = [it] * 7
+st = torch.cuda.current_stream().cuda_stream
+ARMS = [(0, 0), (1, 0)]   # (NCHW in place, -)
+PATHS = {"auto": 0, "lists": 4, "inkernel": 5, "buckets": 6}
+
+
+def timed(fn, warm=30, n=200):
+    for _ in range(warm): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def case(label, R, C, H, W, img, ph=8, pw=64, batch=1, path="auto"):
+    f, r = Wk.bench_inputs(R=R, C=C, H=H, W=W, img=img, seed=3, batch=batch)
+    Rt = torch.from_numpy(r).cuda()
+    g = torch.randn(R, C, ph, pw, device="cuda")
+    nb = lib.rroi_align_backward_workspace_bytes(batch, C, H, W, R, ph, pw)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    outs, res = {}, {a: [] for a in ARMS}
+    for arm in ARMS:
+        outs[arm] = torch.full((batch, C, H, W), float("nan"), device="cuda")
+    def go(arm):
+        assert lib.rroi_align_backward_hip(g.data_ptr(), 0.25, batch, R, H, W, C, ph, pw, Rt.data_ptr(),
+                                           outs[arm].data_ptr(), ws.data_ptr(), nb, PATHS[path], st) == 1
+    for rep in range(4):
+        for arm in ARMS:
+            lib.rroi_align_debug_set_bwd_nchw_direct(arm[0])
+            res[arm].append(timed(lambda: go(arm)))
+    lib.rroi_align_debug_set_bwd_nchw_direct(1)
+    if len(ARMS) > 2:
+        scale = float(outs[ARMS[0]].abs().max())
+        ok = all(bool(((outs[ARMS[0]] - outs[a]).abs() <= 1e-5 * scale).all()) for a in ARMS)
+        print(f"{label:40s} " + "  ".join(f"{a}: {min(res[a]):6.1f}" for a in ARMS) + f"  all equal {ok}", flush=True)
+        return
+    # the lists are filled through atomics: the order of a pixel's entries, and with it the last bits of its sums,
+    # changes from call to call on either arm
+    scale = float(outs[ARMS[0]].abs().max())
+    same = bool(((outs[ARMS[0]] - outs[ARMS[1]]).abs() <= 1e-5 * scale).all()) and not bool(outs[ARMS[1]].isnan().any())
+    if not same:
+        d = (outs[ARMS[0]] != outs[ARMS[1]]) | outs[ARMS[1]].isnan()
+        idx = torch.nonzero(d)
+        print("  differing", int(d.sum()), "of", d.numel(), "nan in arm1", int(outs[ARMS[1]].isnan().sum()), "first", idx[:6].tolist(),
+              "channels", idx[:, 1].unique()[:16].tolist(), "x", idx[:, 3].unique()[:16].tolist(), "y", idx[:, 2].unique()[:8].tolist())
+        i = idx[0].tolist()
+        print("  vals", float(outs[ARMS[0]][tuple(i)]), float(outs[ARMS[1]][tuple(i)]))
+    print(f"{label:40s} scratch+relayout {min(res[ARMS[0]]):7.1f} us   NCHW in place {min(res[ARMS[1]]):7.1f} us   equal {same}", flush=True)
+
+
+case("cfg3 512x256 160x160 8x64", 512, 256, 160, 160, 640)
+if os.environ.get("RROI_AB_ONLY_CFG3"):
+    sys.exit(0)
+case("cfg3, exact lists", 512, 256, 160, 160, 640, path="lists")
+case("train 512x64 120x160 11x83", 512, 64, 120, 160, 640, ph=11, pw=83, path="buckets")
+case("train 32x64 120x160 11x100 b2", 32, 64, 120, 160, 640, ph=11, pw=100, batch=2, path="buckets")
+case("train 512x64 11x83, lists inside the gather", 512, 64, 120, 160, 640, ph=11, pw=83, path="inkernel")
+case("train 32x64 b2, lists inside the gather", 32, 64, 120, 160, 640, ph=11, pw=100, batch=2, path="inkernel")
+case("train 128x64 176x320 11x96", 128, 64, 176, 320, 1280, ph=11, pw=96, path="buckets")
+case("train 128x64 176x320, inside the gather", 128, 64, 176, 320, 1280, ph=11, pw=96, path="inkernel")
+case("512x128 160x160", 512, 128, 160, 160, 640)
+case("512x128 160x160, inside the gather", 512, 128, 160, 160, 640, path="inkernel")
+case("32x128 160x160", 32, 128, 160, 160, 640, path="buckets")
+case("32x128 160x160, inside the gather", 32, 128, 160, 160, 640, path="inkernel")
+case("512x32 160x160", 512, 32, 160, 160, 640, path="buckets")
+case("512x512 80x80 (two passes)", 512, 512, 80, 80, 320)
+case("odd map 256x96 61x77", 256, 96, 61, 77, 300, path="buckets")
+case("odd map 256x256 61x78", 256, 256, 61, 78, 300, path="buckets")
+case("2048x256 160x160", 2048, 256, 160, 160, 640)
+case("16x256 160x160", 16, 256, 160, 160, 640, path="buckets")
