@@ -95,7 +95,10 @@ struct Tuning {
     // leaves no dirty lines for the end of the launch to flush.  Non-temporal LOADS in the gather: +16 us.
     int bwd_relayout_aux = 16;
     int bwd_buckets = 1;          // one-pass pixel lists (round 3); 0: count / scan / fill as in rounds 1-2
-    int bwd_nchw_direct = 1;      // the list gather stores an NCHW bottom_diff itself where that pays (round 4); 0: never
+    int bwd_tile_run = 2;         // the in-place NCHW gather: 2^v neighbouring key tiles per XCD turn
+    int bwd_skip_dead = 1;        // the relayout of top_diff leaves out the bins that enter no list (round 4)
+    int bwd_nchw_direct = 16;     // the list gather stores an NCHW bottom_diff itself (round 4): always for C <= 128, up to this
+                                  // many bins per map pixel beyond; 0: never
 };
 #ifdef RROI_EXPLORE
 Tuning g_tune;
@@ -807,7 +810,8 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
     hipLaunchKernelGGL((rroi_bwd_pairs_relayout_kernel<0, SAUX>), dim3((unsigned)blocks), dim3(256), 0,       \
                        stream, ws.aff, num_rois, height, width, pooled_width, NB, batch_size, lines_per_roi, \
                        dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs, 0, top_diff, ws.tdT, channels,       \
-                       nchunks, tt, (int)blocks, 0, (int)tiles, ws.scan_blocks, 0)
+                       nchunks, tt, (int)blocks, 0, (int)tiles, ws.scan_blocks, 0,                          \
+                       BucketLists{0u, nullptr, nullptr, nullptr}, g_tune.bwd_skip_dead)
 #ifdef RROI_EXPLORE
             if (g_tune.bwd_relayout_aux == 2) RROI_LAUNCH_R(2);
             else if (g_tune.bwd_relayout_aux == 0) RROI_LAUNCH_R(0);
@@ -879,7 +883,7 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
                        dim3(256), 0, stream, ws.aff, num_rois, height, width, pooled_width, NB,          \
                        batch_size, lines_per_roi, dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs,       \
                        pblocks, top_diff, ws.tdT, channels, nchunks, tt, (int)(BLOCKS), (int)(T0), (int)(T1),            \
-                       ws.scan_blocks, raw_bsum, BL)
+                       ws.scan_blocks, raw_bsum, BL, g_tune.bwd_skip_dead)
         if (buckets) {
             // ONE launch: every pair into its pixel's bucket (or overflow chain) || the whole relayout
             const long blocks = relayout_grid(tiles);
@@ -919,13 +923,14 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
         unsigned sub_shift = 3;  // 8 lanes = one chunk
         while ((1u << sub_shift) < 8u * (unsigned)nchunks && sub_shift < 6) ++sub_shift;
         // NCHW bottom_diff written in place (round 4; tools/bwd_nchw_ab.py, profiles/r04_bwd_nchw_ab.txt): a workgroup
-        // needs whole rows (8 pixels) of a key tile, i.e. at most 32 lanes per pixel -- wider pixels deal their
-        // passes of four chunks to blockIdx.y.  cfg3 128.5 -> 124.1 us, C = 64 / 128 at R = 512 87.9 -> 82.4 / 78.4 ->
-        // 74.5, R = 16...32 35.7 -> 29.3 / 23.8 -> 19.2 (the relayout launch was a fifth of those calls); where the
-        // lists are long (41 bins per map pixel) the workgroup's wait for its slowest pixel costs what the
-        // launch saved (2048 x 256: 577 / 580; 512 x 512 on 80 x 80: 272 / 278): the scratch form stays there.
+        // needs whole rows (8 pixels) of a key tile, i.e. at most 32 lanes per pixel -- wider pixels (C > 128) deal
+        // their passes of four chunks to blockIdx.y, which walks every list once per pass: that pays while the lists
+        // are short (cfg3, 10 bins per map pixel: 125.6 -> 117.5 us; 20 per pixel: 274 -> 283), so C > 128 keeps the
+        // scratch form beyond 16 bins per pixel.  C <= 128 gains at every density measured: R = 512, C = 64 / 128
+        // 76.0 -> 71.9 / 76.5 -> 71.2, R = 16...32 36.8 -> 29.0 / 24.3 -> 17.9 (the relayout launch was a fifth of
+        // those calls), 84 bins per pixel 159 -> 153.
         const bool nchw_direct = !bd_nhwc && g_tune.bwd_nchw_direct != 0 &&
-                                 (double)num_rois * NB <= 24.0 * (double)batch_size * HW;
+                                 (nchunks <= 4 || (double)num_rois * NB <= (double)g_tune.bwd_nchw_direct * (double)batch_size * HW);
         unsigned gy = 1;
         if (nchw_direct && sub_shift == 6) {
             sub_shift = 5;
@@ -934,14 +939,15 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
         const unsigned groups_per_block = 256u >> sub_shift;
         // whole groups of 8 key tiles (the kernel deals the tiles of a group to the 8 XCDs)
         const long wg_per_tile = 32 / groups_per_block;  // 1, 2, 4 or 8
-        const long gblocks = ceil_div(ceil_div((long)KL.keys, 32L), 8L) * 8L * wg_per_tile;
+        const unsigned tile_run = nchw_direct ? (unsigned)g_tune.bwd_tile_run : 0u;
+        const long gblocks = ceil_div(ceil_div((long)KL.keys, 32L), 8L << tile_run) * (8L << tile_run) * wg_per_tile;
         // the lists: count / scan / fill segments (`off` = scanned offsets) or buckets (`off` = the counters)
         const unsigned* loff = buckets ? reinterpret_cast<const unsigned*>(ws.cnt) : ws.off;
 #define RROI_LAUNCH_G(DSTK, BUCK, DST)                                                                        \
     hipLaunchKernelGGL((rroi_bwd_gather_kernel<DSTK, BUCK>), dim3((unsigned)gblocks, gy), dim3(256), 0, stream, \
                        td_nhwc ? top_diff : ws.tdT, loff, ws.bsum, ws.pairs, DST, channels, height, width,    \
                        pitch, nchunks, chunk_stride, line_stride, sub_shift, KL, make_fastdiv(KL.Ht * KL.Wt), \
-                       make_fastdiv(KL.Wt), ws.scan_blocks, raw_bsum, BL)
+                       make_fastdiv(KL.Wt), ws.scan_blocks, raw_bsum, BL, tile_run)
         if (bd_nhwc) {
             if (buckets) RROI_LAUNCH_G(kDstNhwc, true, bottom_diff);
             else RROI_LAUNCH_G(kDstNhwc, false, bottom_diff);

@@ -170,7 +170,8 @@ __global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
     int* __restrict__ cnt, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
     uint2* __restrict__ pairs, int pair_blocks, const float* __restrict__ top_diff,
     float* __restrict__ tdT, int C, int nchunks, int ptiles, int relayout_blocks, int tile_begin,
-    int tile_end, unsigned scan_blocks, int raw_bsum, BucketLists bl = BucketLists{0u, nullptr, nullptr, nullptr})
+    int tile_end, unsigned scan_blocks, int raw_bsum, BucketLists bl = BucketLists{0u, nullptr, nullptr, nullptr},
+    int skip_dead_bins = 1)
 {
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
     if ((int)blockIdx.x < pair_blocks) {
@@ -182,9 +183,16 @@ __global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
         return;
     }
     // block j takes the pixel ranges j, j + blocks, ... of [tile_begin, tile_end), all chunks of each
+    // (round 4) a bin that enters no list is not copied: the list builder's own verdict, bin by bin
+    auto live_bin = [&](int n, unsigned ph, unsigned pw) {
+        if (!skip_dead_bins) return true;   // (the exploration build's A/B arm)
+        bool any = false;
+        bin_pairs(aff[n], ph, pw, height, width, batch_size, L, [&](unsigned, float) { any = true; });
+        return any;
+    };
     relayout_run<SAUX, true, true>(T, top_diff, tdT, C, NB, pooled_width, pooled_width, div_pw, nchunks, ptiles,
                           tile_begin + ((int)blockIdx.x - pair_blocks) * nchunks, relayout_blocks * nchunks, tile_end,
-                          aff, batch_size);
+                          aff, batch_size, live_bin);
 }
 
 // Exclusive scan of cnt[0..N) (N = keys + 1, the last element reads as 0), two levels:
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     const uint2* __restrict__ pairs, float* __restrict__ gcm, int C, int height, int width, int pitch,
     int nchunks, unsigned chunk_stride, unsigned line_stride, unsigned sub_shift, KeyLayout L,
     FastDiv div_bt, FastDiv div_wt, unsigned scan_blocks, int raw_bsum,
-    BucketLists bl = BucketLists{0u, nullptr, nullptr, nullptr})
+    BucketLists bl = BucketLists{0u, nullptr, nullptr, nullptr}, unsigned tile_run = 0u)
 {
     constexpr bool DST_NHWC = DST == kDstNhwc, TO_NCHW = DST >= kDstNchw;
     constexpr unsigned THREADS = 256u, kLogThreads = 8u;
@@ -279,7 +287,11 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     // source lines (the 2 x 2 footprint of a bin), and only an XCD's own L2 can serve them twice.
     const unsigned gshift = sub_shift + 5u - kLogThreads;   // log2(workgroups per key tile)
     const unsigned bq = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
-    const unsigned tile = ((bq >> gshift) << 3) + xcd;  // 8 tiles in flight, one per XCD
+    // 8 runs of 2^tile_run consecutive tiles (neighbours in x) in flight, one run per XCD.  TO_NCHW stores 32-byte
+    // sectors; the four sectors of a 128-byte line belong to four neighbouring tiles, and only if those go through
+    // ONE L2 within a few microseconds of each other does the line leave it as one write request instead of four
+    const unsigned tq = bq >> gshift;
+    const unsigned tile = ((tq >> tile_run) << (3u + tile_run)) + (xcd << tile_run) + (tq & ((1u << tile_run) - 1u));
     const unsigned wg = (tile << gshift) + (bq & ((1u << gshift) - 1u));
     const unsigned tid = wg * THREADS + threadIdx.x;
     const unsigned sub = 1u << sub_shift;              // lanes per pixel (8..64)

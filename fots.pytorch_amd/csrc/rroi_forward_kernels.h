@@ -19,19 +19,32 @@ constexpr int kRelayoutPx = 128;
 // R "images" of PH x PW "pixels").  MASK: image b is ROI b and pixels (ph, pw) with
 // pw > roi_pooled_width (or every pixel of a ROI with an invalid batch index) are bins the
 // forward masks -- nothing reads them again, so they are neither loaded nor written.
+// LIVE (a predicate (image, y, x) -> bool, or NoLive): the backward's sharper form of the same -- a bin none of
+// whose taps passes the backward's bounds (kernel.cu:267-274: the parts of a ROI that hang over the map's edge)
+// enters no pixel's list, so its gradient is neither loaded nor written either.  The predicate must be the list
+// builder's own (bin_pairs): a bin it calls dead is a line of the copy that holds whatever the workspace held.
+struct NoLive {
+    __device__ __forceinline__ bool operator()(int, unsigned, unsigned) const { return true; }
+};
 constexpr int kTP = kRelayoutPx + 4;
 
 // PIXMAJOR: the copy is (image, pixel, nchunks * 32) -- all chunks of a pixel in one nchunks * 128-byte
 // run -- instead of (image, chunk, pixel, 32).  The backward's copy of top_diff uses it: its gather
 // reads the 8 chunks of a bin together, and eight lines of one DRAM page cost less than eight lines 65 KB
 // apart (cfg3: gather 52 -> 39 us).
-template <int AUX, bool MASK, bool PIXMAJOR = false>
+template <int AUX, bool MASK, bool PIXMAJOR = false, class Live = NoLive>
 __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float* __restrict__ nchw,
                                                float* __restrict__ cm, int C, int HW, int width, int pitch,
                                                FastDiv div_w, int nchunks, int ptiles, int first_tile,
                                                int tile_stride, int relayout_tiles,
-                                               const Affine* __restrict__ mask_aff, int mask_batches)
+                                               const Affine* __restrict__ mask_aff, int mask_batches,
+                                               Live is_live = Live{})
 {
+    constexpr bool LIVE = !std::is_same<Live, NoLive>::value;
+    static_assert(!LIVE || PIXMAJOR, "the predicate is evaluated once per pixel range, on its first chunk");
+    // (LIVE) one bit per pixel of a 128-pixel range, evaluated by every wave for itself on the range's first chunk
+    // (two pixels per lane, two ballots): the range being loaded, and the range being stored (loaded a chunk earlier)
+    unsigned long long next_lo = ~0ull, next_hi = ~0ull, cur_lo = ~0ull, cur_hi = ~0ull;
     // [32 ch][128 px] tile, 132-float pitch (16-byte aligned rows for the b128 writes); the
     // pixel index of rows 8m..8m+7 is XORed with 4m so that the transposed ds_read_b32 of
     // phase 2 (8 channel quads x 4 pixels per 32-lane group) hits 32 different banks.
@@ -72,6 +85,16 @@ __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float*
             const unsigned x = gp - y * (unsigned)width;
             const float lim = live_limit(b);
             live = !((float)x > lim) || x + 3u >= (unsigned)width;
+            if (LIVE) {
+                if (k == 0) {   // the chunks of a pixel range follow one another: the verdict holds for all of them
+                    const unsigned g0 = (unsigned)(p0 + lane), g1 = g0 + 64u;
+                    const unsigned y0 = fdiv(g0, div_w), y1 = fdiv(g1, div_w);
+                    next_lo = __ballot(g0 < (unsigned)HW && is_live(b, y0, g0 - y0 * (unsigned)width));
+                    next_hi = __ballot(g1 < (unsigned)HW && is_live(b, y1, g1 - y1 * (unsigned)width));
+                }
+                const unsigned long long half = x4 < 16 ? next_lo : next_hi;
+                live = live && ((half >> (4 * (x4 & 15))) & 0xFull) != 0ull;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -122,6 +145,10 @@ __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float*
         }
         __syncthreads();
         const int cur = tile;
+        if (LIVE && cur % nchunks == 0) {   // the range now stored is the one whose first chunk was loaded last
+            cur_lo = next_lo;
+            cur_hi = next_hi;
+        }
         tile = advance(tile);
         if (tile < relayout_tiles) load_tile(tile);
         {
@@ -146,7 +173,7 @@ __device__ __forceinline__ void relayout_run(float* __restrict__ T, const float*
                 const size_t pix = (size_t)y * pitch + x;
                 // every wave issues its four stores on every path (a pixel that is not written is an
                 // out-of-range offset, dropped by the descriptor check): see the note on s_waitcnt below
-                const bool ok = p0 + p < HW && !(MASK && (float)x > lim);
+                const bool ok = p0 + p < HW && !(MASK && (float)x > lim) && (!LIVE || (((p < 64 ? cur_lo : cur_hi) >> (p & 63)) & 1ull) != 0ull);
                 const __amdgpu_buffer_rsrc_t ws =
                     make_rsrc(dst, PIXMAJOR ? (unsigned)(img_bytes - (size_t)k * kLineBytes) : (unsigned)(slice_stride * 4));
                 buf_store<AUX>(ws, ok ? (unsigned)((pix * px_floats + cq * 4) * 4) : kOOB, v);

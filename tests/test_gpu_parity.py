@@ -203,17 +203,17 @@ def test_more_than_256_channels(ext, oracle):
 
 
 def test_backward_gather_writes_nchw_in_place(ext, oracle):
-    """Round 4: with at most 24 bins per map pixel the list gathers store the caller's NCHW gradient themselves
+    """Round 4: for C <= 128, and beyond that with at most 16 bins per map pixel, the list gathers store the caller's NCHW gradient themselves
     (rroi_bwd_gather_kernel<kDstNchw / kDstNchwAdd>): whole 32-byte sectors of a map row per channel out of an LDS
     tile, no chunk-major scratch, no relayout launch.  Maps whose width is not a multiple of 4 (scalar stores) or
     of 8 / height of 4 (padded key tiles), channel counts that need several passes over blockIdx.y with a ragged last
     chunk (C = 300: 10 chunks in groups of 4), two images; every element of a NaN-filled gradient is written; the
     reference-ABI launcher's accumulating form adds k times the gradient in k calls."""
     stream = torch.cuda.current_stream().cuda_stream
-    for (R, C, H, W, ph, pw, B) in ((40, 300, 37, 61, 8, 32, 2), (64, 96, 61, 77, 8, 64, 1), (24, 256, 30, 44, 11, 83, 1),
+    for (R, C, H, W, ph, pw, B) in ((40, 300, 37, 61, 8, 32, 2), (64, 96, 61, 77, 8, 64, 1), (20, 256, 30, 44, 11, 83, 1),
                                     (64, 20, 33, 50, 8, 64, 1), (32, 130, 40, 56, 8, 64, 3)):
         f, r = Wk.bench_inputs(R=R, C=C, H=H, W=W, img=4 * W, seed=R + C, batch=B)
-        assert R * ph * pw <= 24 * B * H * W
+        assert C <= 128 or R * ph * pw <= 16 * B * H * W
         gout = np.random.default_rng(C).standard_normal((R, C, ph, pw)).astype(np.float32)
         want = oracle.backward_c(gout, r, f.shape, 0.25)
         scale = max(1.0, float(np.abs(want).max()))

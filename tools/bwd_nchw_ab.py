@@ -13,7 +13,11 @@ lib.rroi_align_backward_hip.argtypes = [vp, fl, it, it, it, it, it, it, it, vp, 
 lib.rroi_align_backward_workspace_bytes.restype = sz
 lib.rroi_align_backward_workspace_bytes.argtypes = [it] * 7
 st = torch.cuda.current_stream().cuda_stream
-ARMS = [(0, 0), (1, 0)]   # (NCHW in place, -)
+ARMS = [(0, 0), (16, 0)]   # (NCHW in place up to .. bins per map pixel, relayout skips dead bins)
+if os.environ.get("RROI_AB_DEAD"):
+    ARMS = [(16, 0), (16, 1)]
+if os.environ.get("RROI_AB_RUN"):   # (NCHW in place, log2 of the key tiles per XCD turn)
+    ARMS = [(0, 0), (16, 0), (16, 2), (1000, 2)]
 PATHS = {"auto": 0, "lists": 4, "inkernel": 5, "buckets": 6}
 
 
@@ -41,8 +45,13 @@ def case(label, R, C, H, W, img, ph=8, pw=64, batch=1, path="auto"):
     for rep in range(4):
         for arm in ARMS:
             lib.rroi_align_debug_set_bwd_nchw_direct(arm[0])
+            if os.environ.get("RROI_AB_RUN"):
+                lib.rroi_align_debug_set_bwd_tile_run(arm[1])
+            else:
+                lib.rroi_align_debug_set_bwd_skip_dead(arm[1])
             res[arm].append(timed(lambda: go(arm)))
-    lib.rroi_align_debug_set_bwd_nchw_direct(1)
+    lib.rroi_align_debug_set_bwd_nchw_direct(16)
+    lib.rroi_align_debug_set_bwd_skip_dead(1)
     if len(ARMS) > 2:
         scale = float(outs[ARMS[0]].abs().max())
         ok = all(bool(((outs[ARMS[0]] - outs[a]).abs() <= 1e-5 * scale).all()) for a in ARMS)
@@ -59,7 +68,7 @@ def case(label, R, C, H, W, img, ph=8, pw=64, batch=1, path="auto"):
               "channels", idx[:, 1].unique()[:16].tolist(), "x", idx[:, 3].unique()[:16].tolist(), "y", idx[:, 2].unique()[:8].tolist())
         i = idx[0].tolist()
         print("  vals", float(outs[ARMS[0]][tuple(i)]), float(outs[ARMS[1]][tuple(i)]))
-    print(f"{label:40s} scratch+relayout {min(res[ARMS[0]]):7.1f} us   NCHW in place {min(res[ARMS[1]]):7.1f} us   equal {same}", flush=True)
+    print(f"{label:40s} {ARMS[0]} {min(res[ARMS[0]]):7.1f} us   {ARMS[1]} {min(res[ARMS[1]]):7.1f} us   equal {same}", flush=True)
 
 
 case("cfg3 512x256 160x160 8x64", 512, 256, 160, 160, 640)
@@ -82,3 +91,7 @@ case("odd map 256x96 61x77", 256, 96, 61, 77, 300, path="buckets")
 case("odd map 256x256 61x78", 256, 256, 61, 78, 300, path="buckets")
 case("2048x256 160x160", 2048, 256, 160, 160, 640)
 case("16x256 160x160", 16, 256, 160, 160, 640, path="buckets")
+case("1024x256 160x160 (20 bins per pixel)", 1024, 256, 160, 160, 640)
+case("1536x256 160x160 (31 bins per pixel)", 1536, 256, 160, 160, 640)
+case("1024x128 112x112 (42 bins per pixel)", 1024, 128, 112, 112, 448)
+case("2048x64 112x112 (84 bins per pixel)", 2048, 64, 112, 112, 448)

@@ -32,6 +32,18 @@ int rroi_align_debug_set_wg_trace(unsigned* device_buffer)
 {
     return status_of(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace), &device_buffer, sizeof(device_buffer)));
 }
+int rroi_align_debug_set_bwd_tile_run(int v)
+{
+    const int old = g_tune.bwd_tile_run;
+    g_tune.bwd_tile_run = v;
+    return old;
+}
+int rroi_align_debug_set_bwd_skip_dead(int v)
+{
+    const int old = g_tune.bwd_skip_dead;
+    g_tune.bwd_skip_dead = v;
+    return old;
+}
 int rroi_align_debug_set_bwd_nchw_direct(int v)
 {
     const int old = g_tune.bwd_nchw_direct;
