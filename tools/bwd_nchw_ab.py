@@ -7,7 +7,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import workloads as Wk
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_explore", "librroi_align_hip_explore.so"))
+lib = ctypes.CDLL(os.environ.get("RROI_EXPLORE_LIB") or os.path.join(ROOT, "tools", "_explore", "librroi_align_hip_explore.so"))
 vp, fl, it, sz = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
 lib.rroi_align_backward_hip.argtypes = [vp, fl, it, it, it, it, it, it, it, vp, vp, vp, sz, it, vp]
 lib.rroi_align_backward_workspace_bytes.restype = sz
@@ -47,7 +47,7 @@ def case(label, R, C, H, W, img, ph=8, pw=64, batch=1, path="auto"):
             lib.rroi_align_debug_set_bwd_nchw_direct(arm[0])
             if os.environ.get("RROI_AB_RUN"):
                 lib.rroi_align_debug_set_bwd_tile_run(arm[1])
-            else:
+            elif os.environ.get("RROI_AB_DEAD"):
                 lib.rroi_align_debug_set_bwd_skip_dead(arm[1])
             res[arm].append(timed(lambda: go(arm)))
     lib.rroi_align_debug_set_bwd_nchw_direct(16)
