@@ -294,6 +294,13 @@ __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois,
 // ------------------------------------------------------------------------------------
 constexpr int kStoreAux = 2;      // output stores stream (nt) ...
 constexpr int kMinorStores = 1;   // ... except this many of a tile's eight, which go out write-through (kMinorAux)
+// The SHIFT form's windows are HALF lines (16 rows x 64 B per instruction): streamed, each half is a write request of
+// its own (4.36 TB/s for the pattern, store-only); write-through (sc1) lets the L2 put a line's halves together:
+// 6.5 TB/s (tools/kbench win48, profiles/r04_win48_store_policy.txt; plain write-back 5.9-6.1)
+#ifndef RROI_SHIFT_AUX
+#define RROI_SHIFT_AUX 16
+#endif
+constexpr int kShiftAux = RROI_SHIFT_AUX;
 // Workgroup barrier that orders LDS traffic only: s_barrier does not wait for vector memory, and unlike
 // __syncthreads() nothing here makes the compiler emit s_waitcnt vmcnt(0).
 __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -602,7 +609,11 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     //     a quad-swizzled tile, two addresses and three selects per piece: 145 against 147 us at C = 256, 11 x 100, with
     //     a quarter more instructions in the storer; not kept.  profiles/r04_shift_forms.md)
     auto drain_shift = [&](unsigned n, unsigned t, unsigned long long cur_mask, bool skip) {
-        const unsigned ch16 = lane & 15u, pcl = lane >> 4;
+        // lane = (row of sixteen, 16-byte piece of the sector) with the PIECE fastest: the four lanes of a 64-byte sector
+        // are neighbours, which is what the TCP coalesces -- 15 tag accesses per store instruction; with the row
+        // fastest (rounds 3-4: an LDS read without bank conflicts) every lane was an access of its own, 61 per
+        // instruction, and the stores took the TCP from the gatherer's tap loads (tools/kbench desync, PMC)
+        const unsigned ch16 = lane >> 2, pcl = lane & 3u;
         const unsigned nb15 = (unsigned)NB & 15u;
         // float index of (roi n, first channel of the chunk, bin 0), modulo a sector -- out's own alignment included
         const unsigned h0 = (((unsigned)(reinterpret_cast<size_t>(out) >> 2) & 15u) +
@@ -616,6 +627,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         v4f o[kChunk / 4];
 #pragma unroll
         for (int i = 0; i < kChunk / 4; ++i) {
+            if ((i >> 1) == 3 && !last) continue;   // the fourth sector exists in a row's last tile only
             const float* wp = wb + (i & 1) * 16 + (i >> 1) * 16 * kChunk;
             o[i] = v4f{wp[0], wp[kChunk], wp[2 * kChunk], wp[3 * kChunk]};
         }
@@ -647,6 +659,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         const unsigned msh = 16u + 4u * pcl - h;                // the lane that gathered this lane's first element of sector 0
 #pragma unroll
         for (int i = 0; i < kChunk / 4; ++i) {
+            if ((i >> 1) == 3 && !last) continue;
             const unsigned r = ch16 + 16u * (i & 1);
             const int p0 = 16 * (i >> 1) + 4 * (int)pcl;
             // bins in no group (masked by pw > roi_pooled_width, or outside the row) are zero
@@ -657,8 +670,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             // float offset of position p0 within the (roi, chunk) block; never negative where `whole`
             const unsigned off = (r * (unsigned)NB + t * (unsigned)kOwnBins + (unsigned)p0 - h) * 4u;
             const unsigned o_off = (live && whole && r < chans_here) ? off : kOOB;
-            if (i < kMinorStores) buf_store<kMinorAux>(ws, o_off, v);
-            else buf_store<kStoreAux>(ws, o_off, v);
+            buf_store<kShiftAux>(ws, o_off, v);
         }
         if (first || last) {
 #pragma unroll
@@ -666,8 +678,8 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                 const int pa = pl + (int)fi + 2 * ps, pb = (ph & ~3) + (int)fi + 2 * ps;
                 const bool oka = live && fr < chans_here && pa < ((pl + 3) & ~3) && pa < ph;
                 const bool okb = live && fr < chans_here && pb < ph && pb >= pl && (ph & ~3) >= ((pl + 3) & ~3);
-                buf_store1<kStoreAux>(ws, oka ? (fr * (unsigned)NB + t * (unsigned)kOwnBins + (unsigned)pa - fh) * 4u : kOOB, fix[ps]);
-                buf_store1<kStoreAux>(ws, okb ? (fr * (unsigned)NB + t * (unsigned)kOwnBins + (unsigned)pb - fh) * 4u : kOOB, fix[2 + ps]);
+                buf_store1<kShiftAux>(ws, oka ? (fr * (unsigned)NB + t * (unsigned)kOwnBins + (unsigned)pa - fh) * 4u : kOOB, fix[ps]);
+                buf_store1<kShiftAux>(ws, okb ? (fr * (unsigned)NB + t * (unsigned)kOwnBins + (unsigned)pb - fh) * 4u : kOOB, fix[2 + ps]);
             }
         }
     };
@@ -683,8 +695,20 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // Items of this workgroup: every nslots-th one (SHIFT: a row has ceil(NB / 48) tiles -- the host passes that as
     // ntiles).  Both waves walk the same sequence with next(); kEnd ends it.
     constexpr unsigned kEnd = 0xffffffffu;
+#ifdef RROI_EXPLORE
+    // (dbg & 64: a workgroup takes CONSECUTIVE items -- neighbouring tiles of a row block one after the other)
+    const bool contig = (dbg & 64) != 0;
+    const unsigned per = (items + nslots - 1) / nslots;
+    const unsigned c_end = min(items, (slot + 1u) * per);
+    auto next = [&](unsigned c) -> unsigned {
+        if (contig) return c + 1u < c_end ? c + 1u : kEnd;
+        return c + nslots < items ? c + nslots : kEnd;
+    };
+    unsigned cur = contig ? (slot * per < c_end ? slot * per : kEnd) : (slot < items ? slot : kEnd);
+#else
     auto next = [&](unsigned c) -> unsigned { return c + nslots < items ? c + nslots : kEnd; };
     unsigned cur = slot < items ? slot : kEnd;
+#endif
     if (cur == kEnd) return;
     if (storer) {
         RROI_TRACE(0);

@@ -7,7 +7,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import workloads as Wk
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_explore", "librroi_align_hip_explore.so"))
+lib = ctypes.CDLL(os.environ.get("RROI_EXPLORE_LIB") or os.path.join(ROOT, "tools", "_explore", "librroi_align_hip_explore.so"))
 vp, fl, it, sz = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
 lib.rroi_align_forward_stages_hip.argtypes = [vp, it, fl, it, it, it, it, it, it, it, vp, vp, vp, sz, it, it, vp]
 lib.rroi_align_forward_workspace_bytes.restype = sz
@@ -46,7 +46,10 @@ if os.environ.get("RROI_ALIGN_PMC"):   # a few launches of four cases for a coun
         for _ in range(warm + n): fn()
         torch.cuda.synchronize()
         return 0.0
-    case(64, 11, 96); case(64, 11, 100); case(256, 11, 96); case(256, 11, 100)
+    if os.environ["RROI_ALIGN_PMC"] == "256":
+        case(256, 11, 96); case(256, 11, 100)
+    else:
+        case(64, 11, 96); case(64, 11, 100); case(256, 11, 96); case(256, 11, 100)
     sys.exit(0)
 print("shift 1 = what the library does (SHIFT kernels where they pay), 0 = strided items only, 2 = SHIFT forced")
 for C in (64, 256):

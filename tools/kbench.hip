@@ -176,16 +176,22 @@ __global__ __launch_bounds__(64) void k_store_mix(float* __restrict__ out, int n
 //   16 = on 64-byte sectors only, 4 = on 16-byte pieces only.  The buffer is allocated with room for the skew.
 // the SHIFT form's own pattern: tiles of 48 floats per row (three sectors), 16 rows x 64 B per instruction, six
 // instructions per tile; rows of NBX floats (NBX % 16 != 0 gives every row its own phase h, windows start at -h)
-template <int NBX, int WIN = 48, int ORDER = 0>
+// LANES 0: lane = (row of 16, 16-byte piece of 4) with the ROW fastest (what the SHIFT storer did until round 4: an LDS
+// read without bank conflicts); 1: the PIECE fastest -- four neighbouring lanes store one 64-byte sector
+template <int NBX, int WIN = 48, int ORDER = 0, int AUXA = 17, int AUXB = 2, int JIT = 0, int LANES = 0>
 __global__ __launch_bounds__(64) void k_store_win48(float* __restrict__ out, int nchunks, unsigned rois)
 {
-    const unsigned lane = threadIdx.x, ch16 = lane & 15u, pcl = lane >> 4;
+    const unsigned lane = threadIdx.x, ch16 = LANES ? lane >> 2 : lane & 15u, pcl = LANES ? lane & 3u : lane >> 4;
     const unsigned k = blockIdx.x % nchunks, slot = blockIdx.x / nchunks, nslots = gridDim.x / nchunks;
     constexpr unsigned ntiles = (NBX + WIN - 1) / WIN;
     const unsigned items = rois * ntiles;
     const v4u v = {1u, 2u, 3u, lane};
     for (unsigned item = slot; item < items; item += nslots) {
         const unsigned n = item / ntiles, t = item % ntiles;
+        if (JIT) {   // desynchronise the waves: 0 ... ~0.8 us of idling, different for every (wave, item)
+            const unsigned hsh = (item * 2654435761u + blockIdx.x * 40503u) >> 28;   // 0..15
+            for (unsigned w = 0; w < hsh; ++w) __builtin_amdgcn_s_sleep(2);          // 64 x 2 clocks at a time
+        }
         const size_t blk = ((size_t)n * 256 + k * 32) * NBX;
         float* obase = out + blk;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, 32u * NBX * 4u);
@@ -199,8 +205,39 @@ __global__ __launch_bounds__(64) void k_store_win48(float* __restrict__ out, int
             const int j = (int)(t * WIN + p0) - (int)h;
             const bool ok = j >= 0 && j + 4 <= NBX;
             const unsigned off = ok ? (r * NBX + (unsigned)j) * 4u : 0x80000000u;
-            if (i < 1) __builtin_amdgcn_raw_buffer_store_b128(v, ws, off, 0, 17);
-            else __builtin_amdgcn_raw_buffer_store_b128(v, ws, off, 0, 2);
+            if (i < 1) __builtin_amdgcn_raw_buffer_store_b128(v, ws, off, 0, AUXA);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, ws, off, 0, AUXB);
+        }
+    }
+}
+
+// what a line-aligned SHIFT form would store: items of 96 floats per row (three 128-byte lines), 8 rows x 128 B per
+// instruction, twelve instructions per item; rows of NBX floats, windows start at -(row offset mod 32)
+template <int NBX, int AUX, int JIT>
+__global__ __launch_bounds__(64) void k_store_win96(float* __restrict__ out, int nchunks, unsigned rois)
+{
+    const unsigned lane = threadIdx.x, ch8 = lane & 7u, pcl = lane >> 3;
+    const unsigned k = blockIdx.x % nchunks, slot = blockIdx.x / nchunks, nslots = gridDim.x / nchunks;
+    constexpr unsigned ntiles = (NBX + 31 + 95) / 96;
+    const unsigned items = rois * ntiles;
+    const v4u v = {1u, 2u, 3u, lane};
+    for (unsigned item = slot; item < items; item += nslots) {
+        const unsigned n = item / ntiles, t = item % ntiles;
+        if (JIT) {
+            const unsigned hsh = (item * 2654435761u + blockIdx.x * 40503u) >> 28;
+            for (unsigned w = 0; w < hsh; ++w) __builtin_amdgcn_s_sleep(2);
+        }
+        const size_t blk = ((size_t)n * 256 + k * 32) * NBX;
+        float* obase = out + blk;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, 32u * NBX * 4u);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const unsigned r = ch8 + 8u * (i & 3), p0 = 32u * (i >> 2) + 4u * pcl;
+            const unsigned h = (unsigned)((blk + (size_t)r * NBX) & 31u);
+            const int j = (int)(t * 96 + p0) - (int)h;
+            const bool ok = j >= 0 && j + 4 <= NBX;
+            const unsigned off = ok ? (r * NBX + (unsigned)j) * 4u : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(v, ws, off, 0, AUX);
         }
     }
 }
@@ -456,12 +493,61 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    if (argc > 1 && std::string(argv[1]) == "bigout") {
+        // does the rate of the half-line windows hold when the output is larger than the 256 MB memory-side cache?
+        float* big;
+        CK(hipMalloc(&big, (size_t)900 * 256 * 1100 * 4));
+        for (int rep = 0; rep < 2; ++rep)
+            for (unsigned rois : {238u, 476u, 900u}) {
+                char nm[128];
+                const double mb = (double)rois * 256 * 1100 * 4 / 1e6;
+                snprintf(nm, 128, "%u ROIs x 256 x 1100 (%.0f MB): 48-float windows, sc1, piece-fastest", rois, mb);
+                report(nm, T.us([&] { hipLaunchKernelGGL((k_store_win48<1100, 48, 0, 16, 16, 1, 1>), dim3(3072), dim3(64), 0, 0, big, 8, rois); }, 30), mb);
+                snprintf(nm, 128, "%u ROIs x 256 x 1100 (%.0f MB): 48-float windows, plain", rois, mb);
+                report(nm, T.us([&] { hipLaunchKernelGGL((k_store_win48<1100, 48, 0, 0, 0, 1, 1>), dim3(3072), dim3(64), 0, 0, big, 8, rois); }, 30), mb);
+                snprintf(nm, 128, "%u ROIs x 256 x 1100 (%.0f MB): 96-float line-aligned windows, sc1", rois, mb);
+                report(nm, T.us([&] { hipLaunchKernelGGL((k_store_win96<1100, 16, 1>), dim3(3072), dim3(64), 0, 0, big, 8, rois); }, 30), mb);
+                snprintf(nm, 128, "%u ROIs x 256 x 1100 (%.0f MB): 96-float line-aligned windows, nt", rois, mb);
+                report(nm, T.us([&] { hipLaunchKernelGGL((k_store_win96<1100, 2, 1>), dim3(3072), dim3(64), 0, 0, big, 8, rois); }, 30), mb);
+            }
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "desync") {
+        // does the write path's rate for HALF-line windows depend on the two halves of a line arriving together?
+        // the same stores with every wave idling a random 0 ... 0.8 us before each item (the idle time itself is hidden:
+        // 12 waves per CU), against line-aligned windows of 96 floats
+        for (int rep = 0; rep < 2; ++rep) {
+            const double mb913 = 287.0 * 256 * 913 * 4 / 1e6, mb1100 = 238.0 * 256 * 1100 * 4 / 1e6;
+            report("48-float windows, 913, sc1, piece-fastest lanes, in step", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 0, 16, 16, 0, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("48-float windows, 913, sc1, piece-fastest lanes, desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 0, 16, 16, 1, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("48-float windows, 913, nt, piece-fastest lanes, desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 0, 2, 2, 1, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("48-float windows, 913, 1/6 sc0sc1 + nt, piece-fastest lanes, desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 0, 17, 2, 1, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("48-float windows, 913, plain, piece-fastest lanes, desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 0, 0, 0, 1, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("48-float windows, 913, sc1, waves in step", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 0, 16, 16, 0>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("48-float windows, 913, sc1, waves desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 0, 16, 16, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("48-float windows, 913, plain, waves desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 0, 0, 0, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("48-float windows, 913, nt, waves desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 0, 2, 2, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("48-float windows, 1100, sc1, waves desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win48<1100, 48, 0, 16, 16, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 238u); }, 50), mb1100);
+            report("96-float line-aligned windows, 913, sc1, in step", T.us([&] { hipLaunchKernelGGL((k_store_win96<913, 16, 0>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("96-float line-aligned windows, 913, sc1, desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win96<913, 16, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("96-float line-aligned windows, 913, nt, desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win96<913, 2, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("96-float line-aligned windows, 913, plain, desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win96<913, 0, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 50), mb913);
+            report("96-float line-aligned windows, 1100, sc1, desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win96<1100, 16, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 238u); }, 50), mb1100);
+            report("96-float line-aligned windows, 1100, nt, desynchronised", T.us([&] { hipLaunchKernelGGL((k_store_win96<1100, 2, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 238u); }, 50), mb1100);
+        }
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "win48") {
         // store-only ceiling of the SHIFT form's windows (48 floats per tile and row, sector-aligned), by row length
         for (int rep = 0; rep < 2; ++rep) {
             report("48-float windows, rows of 1100 floats (11 x 100), 238 ROIs", T.us([&] { hipLaunchKernelGGL(k_store_win48<1100>, dim3(3072), dim3(64), 0, 0, out, 8, 238u); }, 100), 238.0 * 256 * 1100 * 4 / 1e6);
             report("48-float windows, rows of 913 floats (11 x 83), 287 ROIs", T.us([&] { hipLaunchKernelGGL(k_store_win48<913>, dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
             report("48-float windows, rows of 1056 floats (11 x 96), 248 ROIs", T.us([&] { hipLaunchKernelGGL(k_store_win48<1056>, dim3(3072), dim3(64), 0, 0, out, 8, 248u); }, 100), 248.0 * 256 * 1056 * 4 / 1e6);
+            report("48-float windows, 1100, plain stores (write-back: the L2 may merge a line's halves)", T.us([&] { hipLaunchKernelGGL((k_store_win48<1100, 48, 0, 0, 0>), dim3(3072), dim3(64), 0, 0, out, 8, 238u); }, 100), 238.0 * 256 * 1100 * 4 / 1e6);
+            report("48-float windows, 913, plain stores", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 0, 0, 0>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
+            report("48-float windows, 913, plain stores, a row's sectors back to back", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 1, 0, 0>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
+            report("48-float windows, 913, 1/6 write-through + plain", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 0, 17, 0>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
+            report("48-float windows, 913, all write-through (sc1)", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 0, 16, 16>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
             report("48-float windows, 1100, a row's sectors back to back", T.us([&] { hipLaunchKernelGGL((k_store_win48<1100, 48, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 238u); }, 100), 238.0 * 256 * 1100 * 4 / 1e6);
             report("48-float windows, 913, a row's sectors back to back", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 48, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);
             report("64-float windows, 913, a row's sectors back to back", T.us([&] { hipLaunchKernelGGL((k_store_win48<913, 64, 1>), dim3(3072), dim3(64), 0, 0, out, 8, 287u); }, 100), 287.0 * 256 * 913 * 4 / 1e6);

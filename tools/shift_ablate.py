@@ -7,7 +7,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import workloads as Wk
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_explore", "librroi_align_hip_explore.so"))
+lib = ctypes.CDLL(os.environ.get("RROI_EXPLORE_LIB") or os.path.join(ROOT, "tools", "_explore", "librroi_align_hip_explore.so"))
 vp, fl, it, sz = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
 lib.rroi_align_forward_stages_hip.argtypes = [vp, it, fl, it, it, it, it, it, it, it, vp, vp, vp, sz, it, it, vp]
 lib.rroi_align_forward_workspace_bytes.restype = sz
@@ -46,7 +46,11 @@ for shift, name in ((2, "SHIFT"), (0, "strided")):
         lib.rroi_align_debug_set_fwd_dbg(dbg)
         t = timed(lambda: go(2))
         print(f"  {name:8s} ablation {dbg} (1: stores dropped, 2: taps out of range): {t:7.1f} us  {mb / t / 1e3:5.2f} TB/s")
+lib.rroi_align_debug_set_fwd_shift(2, 0, 0)
+lib.rroi_align_debug_set_fwd_dbg(64)
+print(f"  SHIFT, a workgroup takes consecutive items (dbg 64): {timed(lambda: go(2)):7.1f} us")
 lib.rroi_align_debug_set_fwd_dbg(0)
+print(f"  SHIFT, items every n-th (ships):                     {timed(lambda: go(2)):7.1f} us")
 for wgs in (0, 10, 8):
     lib.rroi_align_debug_set_fwd_shift(2, wgs, 0)
     t = timed(lambda: go(2))
