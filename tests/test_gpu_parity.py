@@ -236,6 +236,41 @@ def test_backward_gather_writes_nchw_in_place(ext, oracle):
                 assert np.abs(gin.cpu().numpy() - k * want).max() <= 3 * BWD_RTOL * scale, (R, C, k)
 
 
+def test_backward_relayout_leaves_out_dead_bins_only(ext, oracle):
+    """Round 4: the relayout of top_diff neither reads nor writes a bin that enters no pixel's list (all four taps fail
+    kernel.cu:267-274: the parts of a ROI that hang over the map's edge, masked columns, foreign batch indices).  The
+    workspace is filled with NaN bit patterns first: a single list entry that named a left-out bin would put a NaN
+    into the gradient.  ROIs centred on and beyond every edge and corner, every angle, on all gather paths."""
+    rng = np.random.default_rng(123)
+    B, C, H, W, ph, pw = 2, 96, 37, 52, 8, 40
+    R = 160
+    rois = np.zeros((R, 6), np.float32)
+    rois[:, 0] = rng.integers(-1, B + 1, R)                       # some foreign batch indices
+    edge = rng.integers(0, 4, R)
+    rois[:, 1] = np.where(edge == 0, rng.uniform(-30, 10, R), np.where(edge == 1, rng.uniform(4 * W - 10, 4 * W + 30, R),
+                                                                    rng.uniform(0, 4 * W, R)))
+    rois[:, 2] = np.where(edge == 2, rng.uniform(-30, 10, R), np.where(edge == 3, rng.uniform(4 * H - 10, 4 * H + 30, R),
+                                                                    rng.uniform(0, 4 * H, R)))
+    rois[:, 3] = rng.uniform(8, 48, R)
+    rois[:, 4] = rois[:, 3] * rng.uniform(1, 6, R)
+    rois[:, 5] = rng.uniform(-180, 180, R)
+    gout = rng.standard_normal((R, C, ph, pw)).astype(np.float32)
+    ok = (rois[:, 0] >= 0) & (rois[:, 0] < B)     # (the reference, and with it the oracle, reads out of bounds for the others;
+    want = oracle.backward_c(gout[ok], rois[ok], (B, C, H, W), 0.25)      # the product gives them no gradient)
+    scale = max(1.0, float(np.abs(want).max()))
+    G, Rr = dev(gout), dev(rois)
+    nb = ext._lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, ph, pw)
+    stream = torch.cuda.current_stream().cuda_stream
+    for p in (ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL):
+        ws = torch.full((nb,), 0xFF, dtype=torch.uint8, device="cuda")
+        got = torch.full((B, C, H, W), float("nan"), device="cuda")
+        assert ext._lib.rroi_align_backward_hip(G.data_ptr(), 0.25, B, R, H, W, C, ph, pw, Rr.data_ptr(), got.data_ptr(),
+                                                ws.data_ptr(), nb, p, stream) == 1
+        g = got.cpu().numpy()
+        assert np.isfinite(g).all(), p
+        assert np.abs(g - want).max() <= BWD_RTOL * scale, p
+
+
 def test_backward_many_rois_on_one_pixel(ext, oracle):
     """200 identical ROIs: every touched pixel's list holds 200 x its pairs (long lists, the
     counters' hot spots) and untouched pixels must come out exactly zero."""
