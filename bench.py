@@ -38,7 +38,10 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import shutil
 import socket
+import subprocess
+import tempfile
 import sys
 import time
 
@@ -186,6 +189,59 @@ def _spawned(local_rank, world, port, args):
     os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     run(args)
+
+
+def live_traffic(mode, timeout_s=150):
+    """HBM-side bytes per launch of every rroi_* kernel of tools/traffic_probe.py (`mode`: "forward" = the configs[1]
+    call, "backward" = the configs[2] call), measured NOW under `rocprofv3 --kernel-trace --pmc <one counter>` for
+    FETCH_SIZE and WRITE_SIZE in separate passes (never with another trace domain), as MI355X_MICROARCH.md's HBM section
+    prescribes: both counters are in KiB, FETCH_SIZE is doubled on gfx950.  Returns {short kernel name: {"FETCH_SIZE",
+    "WRITE_SIZE" (KiB per launch), "us" (average duration in the counter passes), "launches"}} or None when rocprofv3 is
+    absent, when this process is itself being profiled, when RROI_BENCH_TRAFFIC=0, or when anything about a pass fails
+    -- the caller then falls back to the round's committed passes under profiles/."""
+    if os.environ.get("RROI_BENCH_TRAFFIC", "1") == "0" or shutil.which("rocprofv3") is None:
+        return None
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    import csv
+    import glob
+
+    def short(name):
+        return name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rroi_traffic_", dir="/tmp")
+        try:
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "t", "--",
+                            sys.executable, os.path.join(ROOT, "tools", "traffic_probe.py"), mode],
+                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            per_dispatch, span = {}, {}
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        k = short(row["Kernel_Name"])
+                        if k.startswith("rroi_") and row["Counter_Name"] == counter:
+                            key = (k, path, row["Dispatch_Id"])
+                            per_dispatch[key] = per_dispatch.get(key, 0.0) + float(row["Counter_Value"])
+                            span[key] = (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) / 1e3
+            if not per_dispatch:
+                return None
+            for k in {key[0] for key in per_dispatch}:
+                vals = [v for key, v in per_dispatch.items() if key[0] == k]
+                us = [v for key, v in span.items() if key[0] == k]
+                e = res.setdefault(k, {})
+                e[counter] = sum(vals) / len(vals)
+                e["launches"] = len(vals)
+                e["us"] = round(min(e.get("us", 1e30), sum(us) / len(us)), 1)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if any("FETCH_SIZE" not in e or "WRITE_SIZE" not in e for e in res.values()):
+        return None
+    return res
 
 
 def main():
@@ -541,10 +597,34 @@ def run(args):
             bwd_prof = None
 
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes/launch, if collected
-    if os.path.exists(tpath):
+    traffic_source = None
+    how_live = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
+                "tools/traffic_probe.py %s; FETCH_SIZE doubled (gfx950 tallies 128-byte read requests at 64 B), WRITE_SIZE as is")
+    if world == 1:
+        live = live_traffic("forward")   # two short counter passes over the configs[1] call
+        g = None if live is None else next((v for k, v in live.items() if k.startswith("rroi_fwd_split_kernel")), None)
+        if g is not None:
+            traffic = int(g["FETCH_SIZE"] * 2048 + g["WRITE_SIZE"] * 1024)
+            traffic_source = how_live % ("(the configs[1] call, %d launches per pass: FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB)"
+                                         % (g["launches"], g["FETCH_SIZE"], g["WRITE_SIZE"]))
+        live_b = live_traffic("backward")   # ... and over the configs[2] backward call
+        if live_b is not None:
+            per = {k: {"read_bytes": int(v["FETCH_SIZE"] * 2048), "written_bytes": int(v["WRITE_SIZE"] * 1024)}
+                   for k, v in live_b.items()}
+            bwd_prof = {"source": how_live % "backward (the configs[2] call)",
+                        "what": "rroi_align_backward_hip, PATH_TILED, BASELINE configs[2]",
+                        "kernel_us": {k: v["us"] for k, v in live_b.items()},
+                        "kernel_us_how": "average duration of each launch in the counter passes (profiled clocks run ~3 % "
+                                         "below unprofiled ones)",
+                        "traffic_per_kernel": per,
+                        "traffic_bytes_per_call": sum(v["read_bytes"] + v["written_bytes"] for v in per.values())}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # the round's committed counter passes: the fallback
+    if traffic is None and os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get("gather_kernel_bytes_per_launch")
+            traffic_source = ("profiles/traffic.json: FETCH_SIZE (doubled) + WRITE_SIZE of separate rocprofv3 --pmc passes over "
+                              "this kernel, cold caches -- collected once per round, not in this run (no rocprofv3 here, or "
+                              "RROI_BENCH_TRAFFIC=0, or the pass failed)")
         except Exception:
             traffic = None
 
@@ -563,8 +643,7 @@ def run(args):
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "whole_call_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "traffic": traffic,
-                     "traffic_source": "profiles/traffic.json: FETCH_SIZE (doubled) + WRITE_SIZE of separate rocprofv3 "
-                                       "--pmc passes over this kernel, cold caches -- collected once per round, not in this run",
+                     "traffic_source": traffic_source,
                      "algorithmic_bytes": b_alg,
                      "kernel_ms": {"avg": round(gather_in_step_ms, 5), "alone": round(gather_ms, 5),
                                    "how": "avg: inside the step = max(whole_call_ms_events - prologue_ms_avg, alone) (300 steps "
