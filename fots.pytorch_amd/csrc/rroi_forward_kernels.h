@@ -600,10 +600,10 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     //     ds_write_b32); the eight lanes of a bin fill its row: no bank conflict, no swizzle;
     //   * rows r and r + 16 of a chunk have the same h (16 NB is a multiple of 16), so a storer lane that serves the
     //     channels ch16 and ch16 + 16 has ONE h, and every element it reads -- window positions 16 s + 4 pcl + e of
-    //     those two channels -- sits at a compile-time offset from ONE address: 32 ds_read_b32 with immediates, no
+    //     those two channels -- sits at a compile-time offset from ONE address: 24 ds_read_b32 (32 in a row's last tile) with immediates, no
     //     address arithmetic, whatever h is (round 3 rebuilt every window of a channel-major tile with a funnel of
     //     selects from two ds_read_b128 per row set: two kernels, 96 / 117 VGPRs, 10 / 8 workgroups per CU);
-    //   * a wave store instruction covers 16 channel rows x one whole 64-byte sector (4 lanes x 16 B); a tile is three
+    //   * a wave store instruction covers 16 channel rows x one whole 64-byte sector (4 NEIGHBOURING lanes x 16 B); a tile is three
     //     sectors per row -- four in the last tile of a row, whose window runs on to the row's end.  (The strided
     //     kernel's shape, 4 rows x 256 B per instruction, was built too -- lane = (channel of four, piece of sixteen) on
     //     a quad-swizzled tile, two addresses and three selects per piece: 145 against 147 us at C = 256, 11 x 100, with
