@@ -17,14 +17,20 @@ from rroi_align._ext import rroi_align as ext  # noqa: E402
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 bad = 0
+LARGE = bool(os.environ.get("FUZZ_LARGE"))   # FUZZ_LARGE=1: maps up to 330 x 420, up to 260 ROIs
 for t in range(trials):
     C = int(rng.choice([1, 2, 3, 4, 7, 8, 31, 32, 33, 40, 64, 65, 128, 257, 300]))
     H, W = int(rng.integers(2, 70)), int(rng.integers(2, 100))
+    if LARGE:   # maps of many key tiles, several scan blocks, long pixel-major copies
+        H, W = int(rng.integers(60, 330)), int(rng.integers(60, 420))
     B = int(rng.integers(1, 5))
     ph = int(rng.choice([1, 2, 3, 7, 8, 11, 16]))
     pw = int(rng.integers(1, 100))
     s = float(rng.choice([1.0, 0.5, 0.25, 0.125, 0.3]))
     R = int(rng.integers(1, 60))
+    if LARGE:
+        R = int(rng.integers(1, 260))
+        C = int(rng.choice([8, 32, 40, 64, 96, 128, 160, 256, 300]))
     f, r = Wk.bench_inputs(R=R, C=C, H=H, W=W, img=max(4, int(W / s)), seed=5000 + t, batch=B)
     r[:, 2] = rng.uniform(-5, H / s + 5, R)
     r[:, 1] = rng.uniform(-5, W / s + 5, R)
