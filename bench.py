@@ -593,11 +593,13 @@ def run(args):
     if os.path.exists(bpath):
         try:
             bwd_prof = json.load(open(bpath))
+            bwd_prof["traffic_measured"] = False   # the round's committed passes, not this run
         except Exception:
             bwd_prof = None
 
     traffic = None
     traffic_source = None
+    traffic_measured = False     # True only when the counter passes ran inside THIS bench run
     how_live = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over "
                 "tools/traffic_probe.py %s; FETCH_SIZE doubled (gfx950 tallies 128-byte read requests at 64 B), WRITE_SIZE as is")
     if world == 1:
@@ -605,13 +607,14 @@ def run(args):
         g = None if live is None else next((v for k, v in live.items() if k.startswith("rroi_fwd_split_kernel")), None)
         if g is not None:
             traffic = int(g["FETCH_SIZE"] * 2048 + g["WRITE_SIZE"] * 1024)
+            traffic_measured = True
             traffic_source = how_live % ("(the configs[1] call, %d launches per pass: FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB)"
                                          % (g["launches"], g["FETCH_SIZE"], g["WRITE_SIZE"]))
         live_b = live_traffic("backward")   # ... and over the configs[2] backward call
         if live_b is not None:
             per = {k: {"read_bytes": int(v["FETCH_SIZE"] * 2048), "written_bytes": int(v["WRITE_SIZE"] * 1024)}
                    for k, v in live_b.items()}
-            bwd_prof = {"source": how_live % "backward (the configs[2] call)",
+            bwd_prof = {"traffic_measured": True, "source": how_live % "backward (the configs[2] call)",
                         "what": "rroi_align_backward_hip, PATH_TILED, BASELINE configs[2]",
                         "kernel_us": {k: v["us"] for k, v in live_b.items()},
                         "kernel_us_how": "average duration of each launch in the counter passes (profiled clocks run ~3 % "
@@ -643,6 +646,7 @@ def run(args):
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "whole_call_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "traffic": traffic,
+                     "traffic_measured": traffic_measured,
                      "traffic_source": traffic_source,
                      "algorithmic_bytes": b_alg,
                      "kernel_ms": {"avg": round(gather_in_step_ms, 5), "alone": round(gather_ms, 5),

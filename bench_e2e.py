@@ -26,7 +26,9 @@ for _p in (ROOT, os.path.join(ROOT, "fots.pytorch_amd")):
 from fots_e2e.alphabet import ALPHABET  # noqa: E402
 from fots_e2e.hostcpus import cap_torch_threads  # noqa: E402
 from fots_e2e.model import FOTSNet  # noqa: E402
-from fots_e2e.pipeline import batched, infer_image, preprocess, resize_rule, synthetic_boxes, synthetic_detector_maps  # noqa: E402
+from fots_e2e.pipeline import batched, infer_image, preprocess, resize_rule  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+from e2e_inputs import synthetic_boxes, synthetic_detector_maps  # noqa: E402  (input generators, not product)
 from fots_e2e.weights import deterministic_init  # noqa: E402
 # the baseline leg: the reference's per-word loop (checker / baseline code, kept outside the product package)
 from oracle.e2e_loop_oracle import infer_image_per_box, per_box  # noqa: E402

@@ -30,6 +30,8 @@
 #include <stdint.h>
 
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <atomic>
@@ -76,9 +78,10 @@ int num_cus()
     return cus;
 }
 
-// Launch-shape constants of the shipped configuration.  The product reads them as compile-time constants; the
-// exploration build (-DRROI_EXPLORE: tools/kbench.hip, tools/build_explore.sh) makes the struct mutable and adds the
-// rroi_align_debug_set_* setters of tools/rroi_explore_setters.h -- none of that is in the product library.
+// Launch-shape constants of the shipped configuration.  The product reads them as compile-time constants.  The tools'
+// exploration build (tools/rroi_align_hip_explore.hip: kbench, build_explore.sh) includes this file with
+// RROI_TUNING_QUALIFIER defined empty -- a mutable struct -- and adds its rroi_align_debug_set_* setters BEHIND the
+// include: nothing of it is in this file or in the product library.
 struct Tuning {
     int row_pad = -1;             // chunk-major row pitch: -1 = W | 1 (see row_pitch)
     int waves_per_cu = 12;        // the backward's one-wave atomic scatter (rroi_bwd_tiled_kernel): 12.4 KB of LDS each
@@ -89,22 +92,20 @@ struct Tuning {
     int shift_wgs_per_cu = 0;     // > 0 overrides the SHIFT kernels' workgroups per CU
     int fwd_dbg = 0;              // ablations: 1 = skip output stores, 2 = all taps out of range, 256 = free first item
     int prologue_blocks_per_cu = 3;
-    int prologue_aux = 0;         // store policy of the prologue's relayout: 0 plain (ships), 16 write-through
-    // store policy of the backward's top_diff relayout (tools/bwd_profile.py with RROI_BWD_SWEEP=1, four runs):
-    // write-through (sc1) 163.4-165.9 us per call, streaming (nt) 166.8-168.8, plain 166.2-169.2 -- write-through
-    // leaves no dirty lines for the end of the launch to flush.  Non-temporal LOADS in the gather: +16 us.
-    int bwd_relayout_aux = 16;
     int bwd_buckets = 1;          // one-pass pixel lists (round 3); 0: count / scan / fill as in rounds 1-2
     int bwd_tile_run = 2;         // the in-place NCHW gather: 2^v neighbouring key tiles per XCD turn
     int bwd_skip_dead = 1;        // the relayout of top_diff leaves out the bins that enter no list (round 4)
     int bwd_nchw_direct = 16;     // the list gather stores an NCHW bottom_diff itself (round 4): always for C <= 128, up to this
                                   // many bins per map pixel beyond; 0: never
 };
-#ifdef RROI_EXPLORE
-Tuning g_tune;
-#else
-constexpr Tuning g_tune{};
+#ifndef RROI_TUNING_QUALIFIER
+#define RROI_TUNING_QUALIFIER constexpr
 #endif
+RROI_TUNING_QUALIFIER Tuning g_tune{};
+// store policy of the backward's top_diff relayout (round 2 sweep, four runs: write-through (sc1) 163.4-165.9 us per
+// call, streaming (nt) 166.8-168.8, plain 166.2-169.2): write-through leaves no dirty lines for the end of the launch
+// to flush.  Non-temporal LOADS in the gather: +16 us.
+constexpr int kBwdRelayoutAux = 16;
 
 // Row pitch (pixels = 128-byte lines) of the chunk-major copy: W plus a pad that makes the
 // pitch odd, so that the lines of vertically adjacent pixels differ in their low address
@@ -323,7 +324,6 @@ bool pick_tiled_bwd(int batch_size, int channels, int height, int width, int num
 // ------------------------------------------------------------------------------------
 enum class FwdKernel {
     kStrided,        // every n-th (roi, tile) item per workgroup, 16-byte stores: crops whose rows are whole sectors
-    kStridedScalar,  // the same with dword stores (PH * PW % 4 != 0) -- small problems only, see shift_pays
     kChannelsLast,   // channels-last crops (R, PH, PW, C)
     kShift,          // SHIFT: overlapped tiles, sector-aligned store windows -- crops whose rows are not whole sectors
 };
@@ -348,13 +348,12 @@ ForwardPlan plan_forward_gather(int num_rois, int channels, int NB, int nchunks,
     // like the strided form's.  It costs 4 / 3 of the gather work per byte and was never slower than the strided items on
     // such crops, from R = 8 to R = 2048 (tools/align_probe.py, profiles/r04_align_probe.txt: R = 32, C = 64, 11 x 83: 6.6
     // against 9.4 us; R = 128, 11 x 100: 13.7 against 16.5; R = 512, 11 x 83: 40 against 209)
-    if (g_tune.fwd_shift && (NB % 16 != 0 || g_tune.fwd_shift == 2)) {
+    if (NB % 4 != 0 || (g_tune.fwd_shift && (NB % 16 != 0 || g_tune.fwd_shift == 2))) {   // (rows of dwords: always)
         const int wpc = g_tune.shift_wgs_per_cu > 0 ? g_tune.shift_wgs_per_cu : kShiftWgsPerCu;
         const int nt = ceil_div(NB, kShiftOwnBins);
         return {FwdKernel::kShift, tiled_grid((long)num_rois * nt, nchunks, wpc), nt, base_dbg};
     }
-    return {NB % 4 == 0 ? FwdKernel::kStrided : FwdKernel::kStridedScalar,
-            tiled_grid((long)num_rois * ntiles, nchunks, g_tune.split_wgs_per_cu), ntiles, base_dbg};
+    return {FwdKernel::kStrided, tiled_grid((long)num_rois * ntiles, nchunks, g_tune.split_wgs_per_cu), ntiles, base_dbg};
 }
 
 // ------------------------------------------------------------------------------------
@@ -362,33 +361,38 @@ ForwardPlan plan_forward_gather(int num_rois, int channels, int NB, int nchunks,
 // one buffer per (device, stream), grown on demand and reused: calls on one stream are ordered, so the
 // next call may overwrite what the previous one left.  No allocator round trip per call, and a call
 // whose buffer exists enqueues kernels only -- it can be captured into a HIP graph.
-// Lifetime rules:
-//   * a buffer that has been handed out WHILE ITS STREAM WAS CAPTURING is baked into a graph: it is PINNED and
-//     never freed again -- not when a later call needs more (that call takes stream-ordered memory of its own),
-//     not by the least-recently-used eviction, not by rroi_align_release_launcher_scratch();
-//   * a call made while capturing whose buffer does not exist (or is too small) takes stream-ordered memory for
-//     that call alone: the graph owns it;
-//   * the table's lock is held from the look-up until the caller has ENQUEUED its launches (ScratchLease), so a
-//     second thread sharing the stream cannot free -- in stream order, ahead of those launches -- a buffer that
-//     the first thread is about to launch on.
+// Lifetime and locking rules:
+//   * a buffer that has been handed out WHILE ITS STREAM WAS CAPTURING is baked into a graph: it is PINNED and from
+//     then on GRAPH-EXCLUSIVE -- never freed (not by a later, larger call, not by the least-recently-used eviction,
+//     not by rroi_align_release_launcher_scratch()) and never handed out again: later eager calls on that stream get
+//     a buffer of their own (a second table entry), later captures take stream-ordered memory that their graph owns.
+//     So a replay of the graph -- on whatever stream -- shares its scratch with nothing but itself;
+//   * a call made while capturing that finds no unpinned buffer of its stream (or one that is too small) takes
+//     stream-ordered memory for that call alone: the graph owns it;
+//   * locks: the TABLE lock covers look-up, creation and eviction only; every entry has its OWN lock, taken before
+//     the table lock is dropped and held until the caller has ENQUEUED its launches (ScratchLease) -- so only callers
+//     of the same (device, stream) entry serialise, and a second thread sharing the stream cannot free, in stream
+//     order and ahead of those launches, a buffer that the first thread is about to launch on.  Lock order: table,
+//     then entry; a lease holder never takes the table lock.
 // ------------------------------------------------------------------------------------
 struct LauncherArena {
-    int device;
-    hipStream_t stream;
-    void* ptr;
-    size_t bytes;
-    unsigned long long last_use;
-    bool pinned;   // handed out during a stream capture: a graph replays with this address
+    bool used = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    unsigned long long last_use = 0;
+    bool pinned = false;   // handed out during a stream capture: a graph replays with this address
+    std::mutex in_use;     // held by the lease of the call that is enqueuing on this buffer
 };
 constexpr int kMaxArenas = 16;
-std::mutex g_arena_mutex;
+std::mutex g_table_mutex;
 LauncherArena g_arenas[kMaxArenas];
-int g_num_arenas = 0;
 unsigned long long g_arena_clock = 0;
 
-// A buffer of at least `bytes` for launches on `stream`, held under the table's lock until give_back().
+// A buffer of at least `bytes` for launches on `stream`, held under its entry's lock until give_back().
 struct ScratchLease {
-    std::unique_lock<std::mutex> lock;
+    std::unique_lock<std::mutex> lock;   // the entry's (empty for a transient buffer)
     void* ptr = nullptr;
     bool transient = false;   // the buffer belongs to this call alone: give_back() returns it in stream order
     hipError_t err = hipSuccess;
@@ -409,61 +413,88 @@ ScratchLease launcher_scratch(hipStream_t stream, size_t bytes)
     if ((L.err = hipGetDevice(&dev)) != hipSuccess) return L;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    L.lock = std::unique_lock<std::mutex>(g_arena_mutex);
     auto take_transient = [&]() {
         L.err = hipMallocAsync(&L.ptr, bytes, stream);
         L.transient = L.err == hipSuccess;
         if (!L.transient) L.ptr = nullptr;
     };
+    std::unique_lock<std::mutex> table(g_table_mutex);
+    // the stream's own, unpinned entry (a pinned one belongs to its graph)
     LauncherArena* a = nullptr;
-    for (int i = 0; i < g_num_arenas; ++i)
-        if (g_arenas[i].device == dev && g_arenas[i].stream == stream) a = &g_arenas[i];
-    if (a && a->bytes >= bytes) {
-        a->last_use = ++g_arena_clock;
-        if (capturing) a->pinned = true;
-        L.ptr = a->ptr;
-        return L;
-    }
-    // no cached buffer of that size.  While capturing the graph owns what it allocates; a pinned buffer that is
-    // too small stays as it is (a graph replays with it) and this call takes memory of its own
-    if (capturing || (a && a->pinned)) {
-        take_transient();
-        return L;
-    }
-    if (!a) {
-        if (g_num_arenas == kMaxArenas) {
-            // evict the least recently used buffer that no graph holds (its stream may be gone: a synchronous free)
-            int lru = -1;
-            for (int i = 0; i < g_num_arenas; ++i)
-                if (!g_arenas[i].pinned && (lru < 0 || g_arenas[i].last_use < g_arenas[lru].last_use)) lru = i;
-            if (lru < 0) {   // every entry is pinned: nothing to cache this stream's buffer in
-                take_transient();
-                return L;
-            }
-            int cur = dev;
-            (void)hipSetDevice(g_arenas[lru].device);
-            (void)hipFree(g_arenas[lru].ptr);
-            (void)hipSetDevice(cur);
-            g_arenas[lru] = g_arenas[--g_num_arenas];
+    for (LauncherArena& e : g_arenas)
+        if (e.used && !e.pinned && e.device == dev && e.stream == stream) a = &e;
+    if (a) {
+        std::unique_lock<std::mutex> mine(a->in_use);   // (waits for a call that is enqueuing on this entry)
+        if (a->bytes >= bytes) {
+            a->last_use = ++g_arena_clock;
+            if (capturing) a->pinned = true;            // this graph's from now on
+            L.ptr = a->ptr;
+            L.lock = std::move(mine);
+            return L;
         }
-        a = &g_arenas[g_num_arenas++];
-        *a = LauncherArena{dev, stream, nullptr, 0, 0, false};
-    } else {
-        // grow: the old buffer goes back in stream order, behind the launches that still use it (the lock is held
-        // by every caller until its launches are enqueued, so none of them can come after this free)
+        if (capturing) {   // too small, and the graph owns what it allocates: the entry stays as it is
+            mine.unlock();
+            table.unlock();
+            take_transient();
+            return L;
+        }
+        // grow: the old buffer goes back in stream order, behind the launches that still use it (every user held
+        // this entry's lock until its launches were enqueued, so none of them can come after this free)
         if ((L.err = hipFreeAsync(a->ptr, stream)) != hipSuccess) return L;
         a->ptr = nullptr;
         a->bytes = 0;
-    }
-    void* p = nullptr;
-    if ((L.err = hipMallocAsync(&p, bytes, stream)) != hipSuccess) {
-        if (a->ptr == nullptr) *a = g_arenas[--g_num_arenas];  // drop the empty entry
+        void* p = nullptr;
+        if ((L.err = hipMallocAsync(&p, bytes, stream)) != hipSuccess) {
+            a->used = false;
+            return L;
+        }
+        a->ptr = p;
+        a->bytes = bytes;
+        a->last_use = ++g_arena_clock;
+        L.ptr = p;
+        L.lock = std::move(mine);
         return L;
     }
-    a->ptr = p;
-    a->bytes = bytes;
-    a->last_use = ++g_arena_clock;
+    if (capturing) {   // nothing cached for this stream: the graph owns what it allocates
+        table.unlock();
+        take_transient();
+        return L;
+    }
+    // a new entry: a free slot, or the least recently used buffer that no graph holds and nobody is enqueuing on
+    LauncherArena* slot = nullptr;
+    for (LauncherArena& e : g_arenas)
+        if (!e.used && !slot) slot = &e;
+    std::unique_lock<std::mutex> mine;
+    if (slot) {
+        mine = std::unique_lock<std::mutex>(slot->in_use);
+    } else {
+        LauncherArena* lru = nullptr;
+        for (LauncherArena& e : g_arenas)
+            if (!e.pinned && (!lru || e.last_use < lru->last_use)) lru = &e;
+        if (lru) mine = std::unique_lock<std::mutex>(lru->in_use, std::try_to_lock);
+        if (!lru || !mine.owns_lock()) {   // every entry is pinned (or the candidate is busy): nothing to cache in
+            table.unlock();
+            take_transient();
+            return L;
+        }
+        int cur = dev;   // (its stream may be gone: a synchronous free)
+        (void)hipSetDevice(lru->device);
+        (void)hipFree(lru->ptr);
+        (void)hipSetDevice(cur);
+        lru->used = false;
+        slot = lru;
+    }
+    void* p = nullptr;
+    if ((L.err = hipMallocAsync(&p, bytes, stream)) != hipSuccess) return L;
+    slot->used = true;
+    slot->device = dev;
+    slot->stream = stream;
+    slot->ptr = p;
+    slot->bytes = bytes;
+    slot->pinned = false;
+    slot->last_use = ++g_arena_clock;
     L.ptr = p;
+    L.lock = std::move(mine);
     return L;
 }
 
@@ -472,7 +503,7 @@ ScratchLease launcher_scratch(hipStream_t stream, size_t bytes)
 // ====================================================================================
 extern "C" {
 
-const char* rroi_align_hip_version(void) { return "rroi_align_hip 0.6.0 gfx950"; }
+const char* rroi_align_hip_version(void) { return "rroi_align_hip 0.7.0 gfx950"; }
 
 size_t rroi_align_forward_workspace_bytes(int batch_size, int channels, int height, int width,
                                           int num_rois, int feature_layout)
@@ -540,6 +571,9 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
                         bool launcher_rest)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (path & ~(0xff | RROI_PATH_TRIG_FP32)) return 0;   // unknown flag bits
+    const int trig = (path & RROI_PATH_TRIG_FP32) ? RROI_TRIG_FP32 : RROI_TRIG_DOUBLE;
+    path &= 0xff;
     if ((stages & ~RROI_STAGE_ALL) || stages == 0) return 0;
     if (top_layout != RROI_LAYOUT_NCHW && top_layout != RROI_LAYOUT_NHWC) return 0;
     const bool out_nhwc = top_layout == RROI_LAYOUT_NHWC;
@@ -572,7 +606,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         direct_grid(num_rois, NB, channels, grid, cslab);
         hipLaunchKernelGGL(rroi_fwd_direct_kernel, grid, dim3(256), 0, stream, features, rois,
                            top_data, (float*)nullptr, (float*)nullptr, num_rois, channels, height,
-                           width, pooled_height, pooled_width, spatial_scale, batch_size, cslab);
+                           width, pooled_height, pooled_width, spatial_scale, trig, batch_size, cslab);
         return launch_status();
     }
 
@@ -605,13 +639,9 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
                        stream, features, ws.cm, channels, HW, width, pitch,                           \
                        make_fastdiv((unsigned)width), nchunks, ptiles, relayout_blocks,               \
                        relayout_tiles, batch_size, rois, num_rois, pooled_height,                     \
-                       spatial_scale, ws.aff, aff_blocks, launcher_rest ? top_data : (float*)nullptr, \
+                       spatial_scale, trig, ws.aff, aff_blocks, launcher_rest ? top_data : (float*)nullptr, \
                        pooled_width)
-#ifdef RROI_EXPLORE
-        if (g_tune.prologue_aux == 16) RROI_LAUNCH_PRO(16);
-        else
-#endif
-        RROI_LAUNCH_PRO(0);
+        RROI_LAUNCH_PRO(0);   // plain stores: the copy stays in the L2s that wrote it (write-through: 1.8 us faster alone, the step is not)
 #undef RROI_LAUNCH_PRO
         const int st = launch_status();
         if (st != 1) return st;
@@ -642,7 +672,6 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
                        dt, dp, plan.dbg)
         switch (plan.kernel) {
         case FwdKernel::kStrided:       RROI_GATHER(true, 0, 6, 3, false, 0); break;   // 62-64 VGPRs, 12.1 KB of LDS: 12 per CU
-        case FwdKernel::kStridedScalar: RROI_GATHER(false, 0, 6, 3, false, 0); break;
         case FwdKernel::kChannelsLast:  RROI_GATHER(true, 2, 5, 2, true, 0); break;    // 91 VGPRs: 10 per CU
         case FwdKernel::kShift:         RROI_GATHER(true, 0, 6, 3, false, 1); break;    // 79 VGPRs, 12.4 KB of LDS: 12 per CU
         }
@@ -650,12 +679,6 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     }
     return launch_status();
 }
-
-// Exploration knobs for the sweeps and ablations quoted in the notebook: tools/rroi_explore_setters.h, compiled only
-// with -DRROI_EXPLORE (tools/kbench.hip, tools/build_explore.sh).  The product library does not export them.
-#ifdef RROI_EXPLORE
-#include "../../tools/rroi_explore_setters.h"
-#endif
 
 int rroi_align_backward_hip(const float* top_diff, float spatial_scale, int batch_size,
                             int num_rois, int height, int width, int channels,
@@ -698,6 +721,9 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
                          void* workspace, size_t workspace_bytes, int path, void* stream_, bool accumulate)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (path & ~(0xff | RROI_PATH_TRIG_FP32)) return 0;   // unknown flag bits
+    const int trig = (path & RROI_PATH_TRIG_FP32) ? RROI_TRIG_FP32 : RROI_TRIG_DOUBLE;
+    path &= 0xff;
     if (top_diff_layout != RROI_LAYOUT_NCHW && top_diff_layout != RROI_LAYOUT_NHWC) return 0;
     if (bottom_diff_layout != RROI_LAYOUT_NCHW && bottom_diff_layout != RROI_LAYOUT_NHWC) return 0;
     const bool td_nhwc = top_diff_layout == RROI_LAYOUT_NHWC, bd_nhwc = bottom_diff_layout == RROI_LAYOUT_NHWC;
@@ -730,7 +756,7 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
         direct_grid(num_rois, NB, channels, grid, cslab);
         hipLaunchKernelGGL(rroi_bwd_direct_kernel, grid, dim3(256), 0, stream, top_diff, rois,
                            bottom_diff, num_rois, channels, height, width, pooled_height,
-                           pooled_width, spatial_scale, batch_size, cslab);
+                           pooled_width, spatial_scale, trig, batch_size, cslab);
         return launch_status();
     }
 
@@ -782,7 +808,7 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
         const int zblocks = nzero ? (int)std::min<long>(ceil_div((long)nzero, 1024), 2L * num_cus()) : 0;
         if (zblocks > ablocks) ablocks = zblocks;
         hipLaunchKernelGGL(rroi_affine_kernel, dim3(ablocks), dim3(256), 0, stream, rois, num_rois, pooled_height,
-                           spatial_scale, ws.aff, ws.cnt, nzero, buckets ? BL.head : (int*)nullptr,
+                           spatial_scale, trig, ws.aff, ws.cnt, nzero, buckets ? BL.head : (int*)nullptr,
                            buckets ? BL.ovcnt : (unsigned*)nullptr);
     }
     int st = launch_status();
@@ -812,12 +838,7 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
                        dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs, 0, top_diff, ws.tdT, channels,       \
                        nchunks, tt, (int)blocks, 0, (int)tiles, ws.scan_blocks, 0,                          \
                        BucketLists{0u, nullptr, nullptr, nullptr}, g_tune.bwd_skip_dead)
-#ifdef RROI_EXPLORE
-            if (g_tune.bwd_relayout_aux == 2) RROI_LAUNCH_R(2);
-            else if (g_tune.bwd_relayout_aux == 0) RROI_LAUNCH_R(0);
-            else
-#endif
-            RROI_LAUNCH_R(16);
+            RROI_LAUNCH_R(kBwdRelayoutAux);
 #undef RROI_LAUNCH_R
             st = launch_status();
             if (st != 1) return st;
@@ -887,33 +908,18 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
         if (buckets) {
             // ONE launch: every pair into its pixel's bucket (or overflow chain) || the whole relayout
             const long blocks = relayout_grid(tiles);
-#ifdef RROI_EXPLORE
-            if (g_tune.bwd_relayout_aux == 2) RROI_LAUNCH_PR(2, 2, blocks, 0, tiles);
-            else if (g_tune.bwd_relayout_aux == 0) RROI_LAUNCH_PR(2, 0, blocks, 0, tiles);
-            else
-#endif
-            RROI_LAUNCH_PR(2, 16, blocks, 0, tiles);
+            RROI_LAUNCH_PR(2, kBwdRelayoutAux, blocks, 0, tiles);
         } else {
         {
             const long blocks = relayout_grid(half);
-#ifdef RROI_EXPLORE
-            if (g_tune.bwd_relayout_aux == 2) RROI_LAUNCH_PR(0, 2, blocks, 0, half);
-            else if (g_tune.bwd_relayout_aux == 0) RROI_LAUNCH_PR(0, 0, blocks, 0, half);
-            else
-#endif
-            RROI_LAUNCH_PR(0, 16, blocks, 0, half);
+            RROI_LAUNCH_PR(0, kBwdRelayoutAux, blocks, 0, half);
         }
         hipLaunchKernelGGL(rroi_scan1_kernel, dim3(ws.scan_blocks), dim3(1024), 0, stream, ws.cnt, ws.off,
                            ws.bsum, KL.keys);
         if (!raw_bsum) hipLaunchKernelGGL(rroi_scan2_kernel, dim3(1), dim3(1024), 0, stream, ws.bsum, ws.scan_blocks);
         {
             const long blocks = relayout_grid(tiles - half);
-#ifdef RROI_EXPLORE
-            if (g_tune.bwd_relayout_aux == 2) RROI_LAUNCH_PR(1, 2, blocks, half, tiles);
-            else if (g_tune.bwd_relayout_aux == 0) RROI_LAUNCH_PR(1, 0, blocks, half, tiles);
-            else
-#endif
-            RROI_LAUNCH_PR(1, 16, blocks, half, tiles);
+            RROI_LAUNCH_PR(1, kBwdRelayoutAux, blocks, half, tiles);
         }
         }
 #undef RROI_LAUNCH_PR
@@ -1001,7 +1007,16 @@ int rroi_align_bin_centres_hip(float spatial_scale, int num_rois, int height, in
                                int pooled_height, int pooled_width, const float* rois,
                                float* geom, void* stream_)
 {
+    return rroi_align_bin_centres_trig_hip(spatial_scale, num_rois, height, width, pooled_height, pooled_width, rois,
+                                           geom, RROI_TRIG_DOUBLE, stream_);
+}
+
+int rroi_align_bin_centres_trig_hip(float spatial_scale, int num_rois, int height, int width,
+                                    int pooled_height, int pooled_width, const float* rois,
+                                    float* geom, int trig_recipe, void* stream_)
+{
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (trig_recipe != RROI_TRIG_DOUBLE && trig_recipe != RROI_TRIG_FP32) return 0;
     if (num_rois < 0 || height <= 0 || width <= 0 || pooled_height <= 0 || pooled_width <= 0)
         return 0;
     if (num_rois == 0) return 1;
@@ -1009,7 +1024,7 @@ int rroi_align_bin_centres_hip(float spatial_scale, int num_rois, int height, in
     const long threads = (long)num_rois * pooled_height * pooled_width;
     hipLaunchKernelGGL(rroi_bin_centres_kernel, dim3(ceil_div(threads, 256)), dim3(256), 0, stream,
                        rois, geom, num_rois, height, width, pooled_height, pooled_width,
-                       spatial_scale);
+                       spatial_scale, trig_recipe);
     return launch_status();
 }
 
@@ -1060,6 +1075,8 @@ int rroi_rbox_decode_hip(const float* segm, const float* rbox, const float* angl
     return launch_status();
 }
 
+int rroi_nms_record_format(void) { return RROI_NMS_RECORD_FORMAT; }
+
 int rroi_nms_merge_host(const void* candidates, int num_candidates, int width, int height, float iou_threshold,
                         float iou_threshold2, float* boxes, int max_boxes)
 {
@@ -1106,20 +1123,6 @@ int rroi_align_write_probe_hip(float* out, size_t num_floats, void* stream_)
     return launch_status();
 }
 
-int rroi_align_set_trig_recipe_hip(int recipe)
-{
-    if (recipe != RROI_TRIG_DOUBLE && recipe != RROI_TRIG_FP32) return 0;
-    // (synchronous, like any write to a __device__ variable: it is ordered behind the launches already enqueued)
-    return status_of(hipMemcpyToSymbol(HIP_SYMBOL(g_trig_recipe), &recipe, sizeof(recipe)));
-}
-
-int rroi_align_get_trig_recipe_hip(void)
-{
-    int recipe = -1;
-    const hipError_t e = hipMemcpyFromSymbol(&recipe, HIP_SYMBOL(g_trig_recipe), sizeof(recipe));
-    return e == hipSuccess ? recipe : -(int)e;
-}
-
 int rroi_align_sincos_probe_hip(const float* angle_deg, int n, float* out, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -1129,6 +1132,19 @@ int rroi_align_sincos_probe_hip(const float* angle_deg, int n, float* out, void*
     hipLaunchKernelGGL(rroi_sincos_probe_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream,
                        angle_deg, n, out);
     return launch_status();
+}
+
+// The reference-ABI launchers have no `path` to carry the trig recipe: they use RROI_TRIG_DOUBLE, unless the process
+// was started with RROI_ALIGN_LAUNCHER_TRIG=fp32 in its environment (read ONCE, at the first launcher call: a constant
+// of the process, not a switch) -- for a drop-in user who wants every bin equal to the reference's own build for
+// this GPU rather than to the correctly rounded recipe.
+static int launcher_trig()
+{
+    static const int t = [] {
+        const char* e = getenv("RROI_ALIGN_LAUNCHER_TRIG");
+        return (e && (!strcmp(e, "fp32") || !strcmp(e, "1"))) ? RROI_TRIG_FP32 : RROI_TRIG_DOUBLE;
+    }();
+    return t;
 }
 
 // ---- the reference's launcher ABI (rroi_align_kernel.h:8-18) ------------------------
@@ -1154,7 +1170,7 @@ int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
     if (!pick_tiled_fwd(1, channels, height, width, num_rois, NB)) {
         hipLaunchKernelGGL(rroi_fwd_direct_kernel, grid, dim3(256), 0, stream, bottom_data, bottom_rois,
                            top_data, con_idx_x, con_idx_y, num_rois, channels, height, width,
-                           pooled_height, pooled_width, spatial_scale, /*batch_size unknown*/ -1,
+                           pooled_height, pooled_width, spatial_scale, launcher_trig(), /*batch_size unknown*/ -1,
                            cslab);
         return launch_status();
     }
@@ -1169,10 +1185,12 @@ int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
     if (!ws) return status_of(lease.err);
     int st = forward_impl(bottom_data, RROI_LAYOUT_NCHW, RROI_LAYOUT_NCHW, spatial_scale, 1, num_rois, height,
                           width, channels, pooled_height, pooled_width, bottom_rois, top_data, ws, bytes,
-                          RROI_PATH_TILED, RROI_STAGE_ALL, stream_, /*launcher_rest*/ true);
+                          RROI_PATH_TILED | (launcher_trig() ? RROI_PATH_TRIG_FP32 : 0), RROI_STAGE_ALL, stream_,
+                          /*launcher_rest*/ true);
     if (st == 1 && con_idx_x) {
         hipLaunchKernelGGL(rroi_con_idx_kernel, grid, dim3(256), 0, stream, bottom_rois, con_idx_x, con_idx_y,
-                           num_rois, channels, height, width, pooled_height, pooled_width, spatial_scale, cslab);
+                           num_rois, channels, height, width, pooled_height, pooled_width, spatial_scale, launcher_trig(),
+                           cslab);
         st = launch_status();
     }
     const hipError_t e = lease.give_back(stream);   // (everything that uses the buffer is enqueued)
@@ -1204,7 +1222,8 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
         if (!ws) return status_of(lease.err);
         const int st = backward_impl(top_diff, RROI_LAYOUT_NCHW, RROI_LAYOUT_NCHW, spatial_scale, batch_size, num_rois,
                                      height, width, channels, pooled_height, pooled_width, bottom_rois, bottom_diff,
-                                     ws, bytes, RROI_PATH_TILED, stream_, /*accumulate*/ true);
+                                     ws, bytes, RROI_PATH_TILED | (launcher_trig() ? RROI_PATH_TRIG_FP32 : 0), stream_,
+                                     /*accumulate*/ true);
         const hipError_t e = lease.give_back(stream);
         return st != 1 ? st : status_of(e);
     }
@@ -1220,21 +1239,20 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
 
 int rroi_align_release_launcher_scratch(void)
 {
-    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    std::lock_guard<std::mutex> table(g_table_mutex);
     int cur = 0;
     (void)hipGetDevice(&cur);
     hipError_t e = hipSuccess;
-    int kept = 0;
-    for (int i = 0; i < g_num_arenas; ++i) {
-        if (g_arenas[i].pinned) {   // a graph replays with this address: it lives as long as the process
-            g_arenas[kept++] = g_arenas[i];
-            continue;
-        }
-        (void)hipSetDevice(g_arenas[i].device);
-        const hipError_t ei = hipFree(g_arenas[i].ptr);  // synchronous: the buffers' streams may be gone
+    for (LauncherArena& a : g_arenas) {
+        if (!a.used || a.pinned) continue;   // pinned: a graph replays with this address, it lives as long as the process
+        std::lock_guard<std::mutex> mine(a.in_use);   // (a call that is enqueuing on it finishes first)
+        (void)hipSetDevice(a.device);
+        const hipError_t ei = hipFree(a.ptr);  // synchronous: the buffers' streams may be gone
         if (ei != hipSuccess) e = ei;
+        a.used = false;
+        a.ptr = nullptr;
+        a.bytes = 0;
     }
-    g_num_arenas = kept;
     (void)hipSetDevice(cur);
     return status_of(e);
 }

@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void rroi_cm_to_nchw_kernel(const float* __res
 __global__ __launch_bounds__(256) void rroi_bwd_direct_kernel(
     const float* __restrict__ top_diff, const float* __restrict__ rois,
     float* __restrict__ bottom_diff, int num_rois, int C, int height, int width,
-    int pooled_height, int pooled_width, float spatial_scale, int batch_size, int cslab)
+    int pooled_height, int pooled_width, float spatial_scale, int trig, int batch_size, int cslab)
 {
     const int NB = pooled_height * pooled_width;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void rroi_bwd_direct_kernel(
     const int n = (int)(gid / NB);
     const int bin = (int)(gid - (long)n * NB);
     const int ph = bin / pooled_width, pw = bin - ph * pooled_width;
-    const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+    const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale, trig);
     if (A.batch < 0 || A.batch >= batch_size) return;
     float bcx, bcy;
     if (!bin_centre(A, ph, pw, height, width, bcx, bcy)) return;  // see rroi_bwd_tiled_kernel

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void rroi_gt_quads_to_rois_kernel(
 
 __global__ void rroi_bin_centres_kernel(const float* __restrict__ rois, float* __restrict__ geom,
                                         int num_rois, int height, int width, int pooled_height,
-                                        int pooled_width, float spatial_scale)
+                                        int pooled_width, float spatial_scale, int trig)
 {
     const int NB = pooled_height * pooled_width;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,7 +109,7 @@ __global__ void rroi_bin_centres_kernel(const float* __restrict__ rois, float* _
     const int n = (int)(gid / NB);
     const int bin = (int)(gid - (long)n * NB);
     const int ph = bin / pooled_width, pw = bin - ph * pooled_width;
-    const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+    const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale, trig);
     float bcx, bcy;
     const bool in_rroi = bin_centre(A, ph, pw, height, width, bcx, bcy);
     geom[gid * 2 + 0] = in_rroi ? bcx : 0.0f;

@@ -59,25 +59,25 @@ __device__ __forceinline__ int f2i_sat(float x)
 }
 
 // The one library-dependent step of the arithmetic recipe (kernel.cu:73-74: `cos(angle)`, `sin(angle)` of a float).
-//   0 (default)  (float)cos((double)angle): the correctly rounded cosine up to a double rounding -- what
-//                oracle/rroi_align_oracle.c evaluates with the host's libm, identical on the device (2.7 M angles,
-//                test_sincos_recipe_matches_host_libm);
-//   1 (opt-in)   cosf(angle) / sinf(angle) in fp32, i.e. this toolchain's device library (ocml) -- what the
-//                reference's OWN sources become when they are built for this GPU.  Neither float cosine is
+//   RROI_TRIG_DOUBLE (0, default)  (float)cos((double)angle): the correctly rounded cosine up to a double rounding --
+//                what oracle/rroi_align_oracle.c evaluates with the host's libm, identical on the device (2.7 M
+//                angles, test_sincos_recipe_matches_host_libm);
+//   RROI_TRIG_FP32 (1, opt-in)     cosf(angle) / sinf(angle) in fp32, i.e. this toolchain's device library (ocml) --
+//                what the reference's OWN sources become when they are built for this GPU.  Neither float cosine is
 //                correctly rounded, so recipe 0 and a float-cosine build differ in the last place for some angles,
 //                and where that meets a rounding tie a bin's sample point moves (15-17 bins per million,
 //                profiles/r03_fuzz_ref*.json); with recipe 1 the product and the reference's build for gfx950
 //                agree in EVERY bin (tests/test_gpu_vs_reference.py::test_ocml_trig_recipe_moves_no_bin).
-// Per device (a __device__ variable); set with rroi_align_set_trig_recipe_hip().
-__device__ int g_trig_recipe = 0;
+// PER CALL since round 5 (the RROI_PATH_TRIG_FP32 bit of an entry point's `path`): a kernel argument of every kernel
+// that derives an affine from ROIs -- stream-ordered, capturable, no device-wide state.
 
 // kernel.cu:58-84.  Every * and + below is one separately rounded fp32
 // operation, in source order; the degree->radian conversion is the
 // reference's double expression (:65); cos/sin are evaluated in double and
 // rounded once to fp32 (recipe shared with oracle/rroi_align_oracle.c) unless
-// the fp32 recipe has been asked for (g_trig_recipe above).
+// the call asked for the fp32 recipe (`trig`, see above).
 __device__ __forceinline__ Affine make_affine(const float* __restrict__ roi, int pooled_height,
-                                              float spatial_scale)
+                                              float spatial_scale, int trig)
 {
     Affine A;
     A.batch = f2i_sat(roi[0]);
@@ -89,7 +89,7 @@ __device__ __forceinline__ Affine make_affine(const float* __restrict__ roi, int
     const float Sx = (w * spatial_scale) / rpw;
     const float Sy = (h * spatial_scale) / (float)pooled_height;
     float Alpha, Beta;
-    if (g_trig_recipe == 1) {
+    if (trig == 1) {
         Alpha = cosf(angle);
         Beta = sinf(angle);
     } else {

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
     const float* __restrict__ nchw, float* __restrict__ cm, int C, int HW, int width, int pitch,
     FastDiv div_w, int nchunks, int ptiles, int relayout_blocks, int relayout_tiles,
     int batch_size, const float* __restrict__ rois, int num_rois, int pooled_height,
-    float spatial_scale, Affine* __restrict__ aff, int aff_blocks = 0, float* __restrict__ rest_out = nullptr,
+    float spatial_scale, int trig, Affine* __restrict__ aff, int aff_blocks = 0, float* __restrict__ rest_out = nullptr,
     int pooled_width = 0)
 {
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
         // index as the reference does, and the gather leaves their crops alone.
         const int n = (int)blockIdx.x - relayout_blocks - aff_blocks;
         if (f2i_sat(rois[(size_t)n * 6]) < batch_size) return;
-        const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+        const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale, trig);
         const int NB = pooled_height * pooled_width;
         for (int bin = tid; bin < NB; bin += 256)
             direct_bin(nchw, A, rest_out, nullptr, nullptr, n, bin, C, HW / width, width, pooled_width, NB, /*trust*/ -1, 0, C);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
     }
     if ((int)blockIdx.x >= relayout_blocks) {
         const int n = ((int)blockIdx.x - relayout_blocks) * 256 + tid;
-        if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+        if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale, trig);
         return;
     }
     relayout_run<AUX, false>(T, nchw, cm, C, HW, width, pitch, div_w, nchunks, ptiles, (int)blockIdx.x,
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
 // instead of paying a memset launch of their own
 // (bucket lists, round 3: also the overflow chains' heads = -1 and the overflow counter = 0)
 __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois, int pooled_height,
-                                   float spatial_scale, Affine* __restrict__ aff, int* __restrict__ zero = nullptr,
+                                   float spatial_scale, int trig, Affine* __restrict__ aff, int* __restrict__ zero = nullptr,
                                    unsigned nzero = 0, int* __restrict__ heads = nullptr,
                                    unsigned* __restrict__ counter = nullptr)
 {
@@ -268,7 +268,7 @@ __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois,
         if (heads) heads[j] = -1;
     }
     if (counter && gid == 0) *counter = 0u;
-    if (gid < (unsigned)num_rois) aff[gid] = make_affine(rois + (size_t)gid * 6, pooled_height, spatial_scale);
+    if (gid < (unsigned)num_rois) aff[gid] = make_affine(rois + (size_t)gid * 6, pooled_height, spatial_scale, trig);
 }
 
 // ------------------------------------------------------------------------------------
@@ -289,7 +289,8 @@ __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois,
 // waves per SIMD (__launch_bounds__) | HID HI groups double-buffered unrolled (2) or rolled (3) | ONHWC channels-last
 // crops | SHIFT crops whose rows are not whole 64-byte sectors: overlapped tiles and sector-aligned store windows,
 // any row offset (see drain_shift).  dbg: bit 0 drops the stores, bit 1
-// the tap loads (ablations), bit 5 the reference-ABI launcher's mode, bit 8 (exploration build) the free first item.
+// the tap loads (ablations), bit 5 the reference-ABI launcher's mode.  (The per-workgroup time stamps, the
+// contiguous-items knob and the free-first-item ablation of round 4 are tools/experiments/r04_wg_trace_instrumentation.patch.)
 // Shipped instantiations: the switch in forward_impl (rroi_align_hip.hip).
 // ------------------------------------------------------------------------------------
 constexpr int kStoreAux = 2;      // output stores stream (nt) ...
@@ -305,16 +306,6 @@ constexpr int kShiftAux = RROI_SHIFT_AUX;
 // __syncthreads() nothing here makes the compiler emit s_waitcnt vmcnt(0).
 __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-#ifdef RROI_EXPLORE
-// exploration: per-workgroup time stamps of the split kernel (100 MHz s_memrealtime, low 32 bits):
-// [8 b + 0] storer entry, + 1 the gatherer's first loads, + 2 the storer's first store, + 3 storer exit,
-// + 4 HW_REG_HW_ID, + 5 HW_REG_XCC_ID, + 6 the time half of the items were drained, + 7 items drained
-__device__ unsigned* g_wg_trace = nullptr;
-#define RROI_TRACE(i) do { if (g_wg_trace && lane == 0) g_wg_trace[8u * blockIdx.x + (i)] = (unsigned)wall_clock64(); } while (0)
-#define RROI_TRACE_V(i, v) do { if (g_wg_trace && lane == 0) g_wg_trace[8u * blockIdx.x + (i)] = (v); } while (0)
-#else
-#define RROI_TRACE(i) do { } while (0)
-#endif
 
 template <bool VEC_STORE, int EARLY, int OCC, int HID, bool ONHWC, int SHIFT>
 __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
@@ -391,7 +382,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // Offsets are byte offsets into the slice; kOOB reads as 0.0, which is what
     // kernel.cu:116-126 substitutes for a tap outside the map.
     auto geometry = [&](const Affine& A, unsigned t, unsigned p, unsigned& n_lo_groups,
-                        unsigned& n_hi_groups, unsigned long long& amask, unsigned min_lane = 0u) {
+                        unsigned& n_hi_groups, unsigned long long& amask) {
         uint4* const G = Gbuf + p * kRecs;
         unsigned char* const HP = HPbuf + p * kRecs;
         // where phase B puts the bin: the lane's index -- its column of the channel-major tile, or (SHIFT) its row of the
@@ -405,7 +396,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         const unsigned pw = bin - ph * (unsigned)pooled_width;
         float bcx, bcy;
         bool active = bin_centre(A, (int)ph, (int)pw, height, width, bcx, bcy);
-        active = active && sbin >= 0 && bin < (unsigned)NB && batch_ok && lane >= min_lane;
+        active = active && sbin >= 0 && bin < (unsigned)NB && batch_ok;
         const float fx = floorf(bcx), fy = floorf(bcy);
         const int x0 = f2i_sat(fx), x1 = f2i_sat(ceilf(bcx));
         const int y0 = f2i_sat(fy), y1 = f2i_sat(ceilf(bcy));
@@ -695,33 +686,10 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // Items of this workgroup: every nslots-th one (SHIFT: a row has ceil(NB / 48) tiles -- the host passes that as
     // ntiles).  Both waves walk the same sequence with next(); kEnd ends it.
     constexpr unsigned kEnd = 0xffffffffu;
-#ifdef RROI_EXPLORE
-    // (dbg & 64: a workgroup takes CONSECUTIVE items -- neighbouring tiles of a row block one after the other)
-    const bool contig = (dbg & 64) != 0;
-    const unsigned per = (items + nslots - 1) / nslots;
-    const unsigned c_end = min(items, (slot + 1u) * per);
-    auto next = [&](unsigned c) -> unsigned {
-        if (contig) return c + 1u < c_end ? c + 1u : kEnd;
-        return c + nslots < items ? c + nslots : kEnd;
-    };
-    unsigned cur = contig ? (slot * per < c_end ? slot * per : kEnd) : (slot < items ? slot : kEnd);
-#else
     auto next = [&](unsigned c) -> unsigned { return c + nslots < items ? c + nslots : kEnd; };
     unsigned cur = slot < items ? slot : kEnd;
-#endif
     if (cur == kEnd) return;
     if (storer) {
-        RROI_TRACE(0);
-#ifdef RROI_EXPLORE
-        {
-            unsigned hw, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            RROI_TRACE_V(4, hw);
-            RROI_TRACE_V(5, xcc);
-        }
-        unsigned drained = 0;
-#endif
         unsigned n = fdiv(cur, div_tiles), t = cur - n * (unsigned)ntiles;
         unsigned p = 0;
         unsigned gl, gh;
@@ -730,25 +698,12 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         // dbg & 32 (the reference-ABI launcher): the crops of ROIs whose image index is >= batch_size have been
         // written by the prologue launch -- they are not zero-filled here
         bool skip_cur = false, skip_prev = false;
-#ifdef RROI_EXPLORE
-        bool first_plan = true;
-#endif
         auto plan = [&](unsigned pn, unsigned pt, unsigned pp, unsigned long long& m) {
             const Affine A = aff[pn];
             skip_cur = (dbg & 32) && A.batch >= batch_size;  // (a negative index still yields zeros)
-#ifdef RROI_EXPLORE
-            // ablation (dbg & 256): the workgroup's FIRST item costs nothing -- no geometry, no taps (its tile is zeros):
-            // an upper bound on what any shortening of the launch's start-up chain can gain
-            geometry(A, pt, pp, gl, gh, m, ((dbg & 256) && first_plan) ? 64u : 0u);
-            first_plan = false;
-#else
             geometry(A, pt, pp, gl, gh, m);
-#endif
             if (lane == 0) shead[pp] = make_uint4(gl, gh, (unsigned)m, (unsigned)(m >> 32));
         };
-#ifdef RROI_EXPLORE
-        bool traced_first = false;
-#endif
         plan(n, t, 0, mask_cur);
         for (bool have_prev = false;; have_prev = true) {
             wg_lds_barrier();  // 1: records of item `cur` are in set p; the tile of the previous item is in T
@@ -756,11 +711,6 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                 // T -> registers | barrier 2 | stores
                 if (SHIFT) drain_shift(n_prev, t_prev, mask_prev, skip_prev);
                 else drain_tile(n_prev, t_prev, mask_prev, skip_prev);
-#ifdef RROI_EXPLORE
-                if (!traced_first) { RROI_TRACE(2); traced_first = true; }
-                if (++drained == 5) RROI_TRACE(6);
-                RROI_TRACE_V(7, drained);
-#endif
             } else {
                 wg_lds_barrier();
             }
@@ -777,7 +727,6 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
                 plan(n, t, p, mask_cur);  // while the gatherer blends the item before
             }
         }
-        RROI_TRACE(3);
         return;
     }
     // the gatherer's chain (records -> loads -> blend) is the latency of a tile; the storer's geometry is
@@ -809,9 +758,6 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         }
         fetch_lo(p, kEarly, 0);
         issue_lo(rs, 0);
-#ifdef RROI_EXPLORE
-        if (cur == slot) RROI_TRACE(1);
-#endif
         wg_lds_barrier();  // 2: the storer holds the previous tile in registers: T is free
 
         // ---- phase B: the loads of group g+1 are issued before group g is blended.  The loops are
@@ -896,7 +842,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
 __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
     const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
     float* __restrict__ idx_x, float* __restrict__ idx_y, int num_rois, int C, int height,
-    int width, int pooled_height, int pooled_width, float spatial_scale, int batch_size,
+    int width, int pooled_height, int pooled_width, float spatial_scale, int trig, int batch_size,
     int cslab)
 {
     const int NB = pooled_height * pooled_width;
@@ -904,7 +850,7 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
     if (gid >= (long)num_rois * NB) return;
     const int n = (int)(gid / NB);
     const int bin = (int)(gid - (long)n * NB);
-    const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+    const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale, trig);
     const int c_begin = blockIdx.y * cslab;
     direct_bin(feat, A, out, idx_x, idx_y, n, bin, C, height, width, pooled_width, NB, batch_size, c_begin,
                min(C, c_begin + cslab));
@@ -915,7 +861,7 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
 // slab; consecutive lanes write consecutive bins.
 __global__ __launch_bounds__(256) void rroi_con_idx_kernel(
     const float* __restrict__ rois, float* __restrict__ idx_x, float* __restrict__ idx_y, int num_rois, int C,
-    int height, int width, int pooled_height, int pooled_width, float spatial_scale, int cslab)
+    int height, int width, int pooled_height, int pooled_width, float spatial_scale, int trig, int cslab)
 {
     const int NB = pooled_height * pooled_width;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -923,7 +869,7 @@ __global__ __launch_bounds__(256) void rroi_con_idx_kernel(
     const int n = (int)(gid / NB);
     const int bin = (int)(gid - (long)n * NB);
     const int ph = bin / pooled_width, pw = bin - ph * pooled_width;
-    const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale);
+    const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale, trig);
     float bcx, bcy;
     const bool in_rroi = bin_centre(A, ph, pw, height, width, bcx, bcy);
     const float vx = in_rroi ? bcx : 0.0f, vy = in_rroi ? bcy : 0.0f;

@@ -16,7 +16,6 @@ The reference's own structure (`tools/ocr_utils.py:131-199`: per WORD a host-bui
 launch, the head, `max(1)`, a Python decode) is not part of this package: it lives with the checkers
 (`oracle/e2e_loop_oracle.py`), where the tests compare the two and `bench_e2e.py` times it as the baseline.
 """
-import math
 
 import numpy as np
 import torch
@@ -50,54 +49,6 @@ def preprocess(im_u8, device):
     if (h, w) != tuple(t.shape[2:]):
         t = F.interpolate(t, size=(h, w), mode="bilinear", align_corners=False)
     return t / 128 - 1
-
-
-def synthetic_boxes(n, height, width, seed=0):
-    """(n, 9) fp32 [x0,y0,x1,y1,x2,y2,x3,y3,score]: word-shaped rotated rectangles inside a
-    height x width image, corner order as `nms.get_boxes` hands them to `align_ocr` (edge 0->1 is
-    the short side, 1->2 the long one).  Stands in for the detector's output while its heads carry
-    random weights (a random score map passes no box, or a hundred thousand, through the NMS)."""
-    rng = np.random.default_rng(seed)
-    out = np.zeros((n, 9), np.float32)
-    for i in range(n):
-        h = rng.uniform(14, 48)
-        w = h * rng.uniform(1.5, 9.0)
-        a = rng.uniform(-25, 25) / 180 * math.pi
-        m = 0.5 * (w + h)
-        cx, cy = rng.uniform(m, max(m + 1, width - m)), rng.uniform(m, max(m + 1, height - m))
-        ux, uy, vx, vy = math.cos(a), math.sin(a), -math.sin(a), math.cos(a)
-        p1 = (cx - ux * w / 2 - vx * h / 2, cy - uy * w / 2 - vy * h / 2)
-        p2 = (p1[0] + ux * w, p1[1] + uy * w)
-        p0 = (p1[0] + vx * h, p1[1] + vy * h)
-        p3 = (p2[0] + vx * h, p2[1] + vy * h)
-        out[i] = (*p0, *p1, *p2, *p3, rng.uniform(0.5, 1.0))
-    return out
-
-
-def synthetic_detector_maps(height, width, nwords, seed=0):
-    """score (h, w), rbox (4, h, w), angle (2, h, w) fp32 numpy at 1/4 of a height x width image: what a
-    TRAINED detector emits for `nwords` rotated words (score inside the shrunk box, distances to the
-    four sides, unit direction) -- input for timing `rroi_align.nms.get_boxes`, which random
-    detection weights cannot exercise."""
-    h, w = height // 4, width // 4
-    rng = np.random.default_rng(seed)
-    segm, geo, ang = np.zeros((h, w), np.float32), np.zeros((4, h, w), np.float32), np.zeros((2, h, w), np.float32)
-    ang[1] = 1
-    ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
-    for _ in range(nwords):
-        cx, cy = rng.uniform(10, w - 10), rng.uniform(6, h - 6)
-        bh = rng.uniform(3, 8)
-        bw = bh * rng.uniform(2, 7)
-        a = rng.uniform(-0.5, 0.5)
-        c, s = np.cos(a), np.sin(a)
-        u = (xs + 0.25 - cx) * c + (ys + 0.25 - cy) * s
-        v = -(xs + 0.25 - cx) * s + (ys + 0.25 - cy) * c
-        inside = (np.abs(u) < bw / 2 * 0.8) & (np.abs(v) < bh / 2 * 0.6)
-        segm[inside] = rng.uniform(0.6, 0.99, inside.sum())
-        for k, d in enumerate((v + bh / 2, bh / 2 - v, u + bw / 2, bw / 2 - u)):
-            geo[k][inside] = np.maximum(d[inside], 0)
-        ang[0][inside], ang[1][inside] = s, c
-    return segm, geo, ang
 
 
 def target_widths_host(boxes):
@@ -163,7 +114,7 @@ def infer_image(net, converter, im, detector=None, segm_thresh=0.5, return_debug
 
     `detector`: optional hook `im_data -> (score (h, w), rbox (4, h, w), angle (2, h, w))` device tensors
     that stand in for the three head outputs -- random weights pass no box (or a hundred thousand)
-    through the NMS, so tests and the benchmark inject `synthetic_detector_maps` here.
+    through the NMS, so tests and the benchmark inject the maps of `tests/e2e_inputs.py: synthetic_detector_maps` here.
 
     Host synchronisations per image: ONE before the head (`get_boxes` reads the number of passing pixels
     and their records: the merge is sequential host code) and the final read-back of the decoded labels.

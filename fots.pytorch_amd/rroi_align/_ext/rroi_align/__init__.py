@@ -73,10 +73,10 @@ _lib.rroi_align_sincos_probe_hip.restype = _i
 _lib.rroi_align_sincos_probe_hip.argtypes = [_vp, _i, _vp, _vp]
 _lib.rroi_align_write_probe_hip.restype = _i
 _lib.rroi_align_write_probe_hip.argtypes = [_vp, _sz, _vp]
-_lib.rroi_align_set_trig_recipe_hip.restype = _i
-_lib.rroi_align_set_trig_recipe_hip.argtypes = [_i]
-_lib.rroi_align_get_trig_recipe_hip.restype = _i
-_lib.rroi_align_get_trig_recipe_hip.argtypes = []
+_lib.rroi_align_bin_centres_trig_hip.restype = _i
+_lib.rroi_align_bin_centres_trig_hip.argtypes = [_f, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]
+_lib.rroi_nms_record_format.restype = _i
+_lib.rroi_nms_record_format.argtypes = []
 _lib.RROIAlignForwardLaucher.restype = _i
 _lib.RROIAlignForwardLaucher.argtypes = [_vp, _f, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.RROIAlignBackwardLaucher.restype = _i
@@ -91,7 +91,7 @@ EXPORTS = (
     "rroi_align_sincos_probe_hip", "rroi_align_quads_to_rois_hip", "rroi_align_hip_version",
     "rroi_ctc_greedy_decode_hip", "rroi_align_backward_layout_hip", "rroi_align_forward_layout_hip",
     "rroi_align_gt_quads_to_rois_hip", "rroi_rbox_decode_hip", "rroi_nms_merge_host",
-    "rroi_align_release_launcher_scratch", "rroi_align_set_trig_recipe_hip", "rroi_align_get_trig_recipe_hip",
+    "rroi_align_release_launcher_scratch", "rroi_align_bin_centres_trig_hip", "rroi_nms_record_format",
     "rroi_align_write_probe_hip",
 )
 
@@ -100,20 +100,19 @@ def version() -> str:
     return _lib.rroi_align_hip_version().decode()
 
 
+# The one library-dependent step of the arithmetic (rroi_align_kernel.cu:73-74): TRIG_DOUBLE (default; the oracle's
+# recipe, (float)cos((double)angle)) or TRIG_FP32 (the device library's cosf / sinf -- what the reference's own sources
+# evaluate when built for this GPU; bit-exact against that build in every bin).  PER CALL since round 5: the `trig=`
+# keyword of forward() / backward() / bin_centres() sets the RROI_PATH_TRIG_FP32 bit of the call's `path`; a kernel
+# argument, so two streams may run different recipes at once and either is capturable into a graph.
 TRIG_DOUBLE, TRIG_FP32 = 0, 1
+PATH_TRIG_FP32 = 0x100
 
 
-def set_trig_recipe(recipe: int, device=None) -> int:
-    """cos / sin of the ROI angle (rroi_align_kernel.cu:73-74) on `device` (default: the current one):
-    TRIG_DOUBLE (default; the oracle's recipe, (float)cos((double)angle)) or TRIG_FP32 (the device library's
-    cosf / sinf -- what the reference's own sources evaluate when built for this GPU; bit-exact against that
-    build in every bin).  Returns the previous recipe.  Synchronises with the device."""
-    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
-        old = _lib.rroi_align_get_trig_recipe_hip()
-        if old < 0:
-            raise RuntimeError(f"rroi_align_get_trig_recipe_hip: HIP error {-old}")
-        _check(_lib.rroi_align_set_trig_recipe_hip(int(recipe)), "rroi_align_set_trig_recipe_hip")
-    return old
+def _path_word(path: int, trig: int) -> int:
+    if trig not in (TRIG_DOUBLE, TRIG_FP32):
+        raise ValueError(f"trig must be TRIG_DOUBLE (0) or TRIG_FP32 (1), got {trig!r}")
+    return int(path) | (PATH_TRIG_FP32 if trig == TRIG_FP32 else 0)
 
 
 def _check(status: int, what: str) -> None:
@@ -181,10 +180,13 @@ def _require_cuda_f32(t: torch.Tensor, name: str) -> None:
 
 # --------------------------------------------------------------------------- native path
 def forward(features: torch.Tensor, rois: torch.Tensor, pooled_height: int, pooled_width: int,
-            spatial_scale: float, path: int = PATH_AUTO, channels_last_out: bool = False) -> torch.Tensor:
+            spatial_scale: float, path: int = PATH_AUTO, channels_last_out: bool = False,
+            trig: int = TRIG_DOUBLE) -> torch.Tensor:
     """(B,C,H,W) x (R,6) -> (R,C,PH,PW).  NCHW-contiguous or channels_last features.
     channels_last_out: return the crops in channels_last storage (same values) for a recognition
-    head that runs in channels_last; needs C % 4 == 0 and the tiled path."""
+    head that runs in channels_last; needs C % 4 == 0 and the tiled path.
+    trig: TRIG_DOUBLE / TRIG_FP32, for this call (pass the same to backward())."""
+    word = _path_word(path, trig)
     _require_cuda_f32(features, "features")
     _require_cuda_f32(rois, "rois")
     if features.dim() != 4:
@@ -217,15 +219,17 @@ def forward(features: torch.Tensor, rois: torch.Tensor, pooled_height: int, pool
         st = _lib.rroi_align_forward_layout_hip(features.data_ptr(), layout,
                                                 LAYOUT_NHWC if channels_last_out else LAYOUT_NCHW,
                                                 float(spatial_scale), B, R, H, W, C, ph, pw, rois.data_ptr(),
-                                                out.data_ptr(), ws.data_ptr(), nbytes, path, _stream())
+                                                out.data_ptr(), ws.data_ptr(), nbytes, word, _stream())
     _check(st, "rroi_align_forward_hip")
     return out
 
 
 def backward(grad_output: torch.Tensor, rois: torch.Tensor, feature_size, spatial_scale: float,
-             path: int = PATH_AUTO, channels_last_grad: bool = False) -> torch.Tensor:
+             path: int = PATH_AUTO, channels_last_grad: bool = False, trig: int = TRIG_DOUBLE) -> torch.Tensor:
     """(R,C,PH,PW) -> grad w.r.t. features (B,C,H,W): NCHW contiguous, or (channels_last_grad, for a
-    channels_last backbone; needs C % 4 == 0 and the tiled path) in channels_last storage."""
+    channels_last backbone; needs C % 4 == 0 and the tiled path) in channels_last storage.
+    trig: the recipe the forward of these crops ran with."""
+    word = _path_word(path, trig)
     _require_cuda_f32(grad_output, "grad_output")
     _require_cuda_f32(rois, "rois")
     B, C, H, W = (int(v) for v in feature_size)
@@ -253,13 +257,13 @@ def backward(grad_output: torch.Tensor, rois: torch.Tensor, feature_size, spatia
         st = _lib.rroi_align_backward_layout_hip(grad_output.data_ptr(), layout,
                                                  LAYOUT_NHWC if cl_grad else LAYOUT_NCHW, float(spatial_scale),
                                                  B, R, H, W, C, ph, pw, rois.data_ptr(), grad_in.data_ptr(),
-                                                 ws.data_ptr(), nbytes, path, _stream())
+                                                 ws.data_ptr(), nbytes, word, _stream())
     _check(st, "rroi_align_backward_hip")
     return grad_in
 
 
 def bin_centres(rois: torch.Tensor, pooled_height: int, pooled_width: int, spatial_scale: float,
-                height: int, width: int) -> torch.Tensor:
+                height: int, width: int, trig: int = TRIG_DOUBLE) -> torch.Tensor:
     """(R,PH,PW,2) sample points (kernel.cu:86-107); zero outside the ROI's pooled width."""
     _require_cuda_f32(rois, "rois")
     rois = rois.contiguous()
@@ -267,10 +271,10 @@ def bin_centres(rois: torch.Tensor, pooled_height: int, pooled_width: int, spati
     with torch.cuda.device_of(rois):
         geom = torch.empty((R, int(pooled_height), int(pooled_width), 2), dtype=torch.float32,
                            device=rois.device)
-        st = _lib.rroi_align_bin_centres_hip(float(spatial_scale), R, int(height), int(width),
-                                             int(pooled_height), int(pooled_width),
-                                             rois.data_ptr(), geom.data_ptr(), _stream())
-    _check(st, "rroi_align_bin_centres_hip")
+        st = _lib.rroi_align_bin_centres_trig_hip(float(spatial_scale), R, int(height), int(width),
+                                                  int(pooled_height), int(pooled_width),
+                                                  rois.data_ptr(), geom.data_ptr(), int(trig), _stream())
+    _check(st, "rroi_align_bin_centres_trig_hip")
     return geom
 
 

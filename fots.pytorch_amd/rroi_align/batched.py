@@ -41,6 +41,9 @@ class BatchedRRoiAlign(Module):
         return crops, gw
 
 
+_warned_ambiguous_jitter = False
+
+
 class GroundTruthRRoiAlign(Module):
     """The training caller's call (src/ocr_process.py:196-221, :253-267): ground-truth quads of a
     batch -> crops for the recognition loss, ROI rows and pooled width computed on the device.
@@ -57,8 +60,8 @@ class GroundTruthRRoiAlign(Module):
     `height_jitter` is the caller's random.randint(-2, 2) (:204): one value per box, or -- what the
     reference draws -- ONE PER IMAGE, a tensor of batch-size length that is then looked up through
     `batch_index`.  Which of the two it is is SAID, not guessed: `per_image_jitter=True` / `False`; left at None
-    the length decides only while it can (a length that equals both the number of boxes and could be a batch
-    size -- e.g. one box per image -- raises instead of silently taking one reading).  Rows whose jittered h is negative yield all-zero crops (the op's
+    the length decides only while it can (a length that equals both the number of boxes and the batch
+    size -- e.g. one box per image -- is read per box, as rounds 1-3 did, with one warning per process).  Rows whose jittered h is negative yield all-zero crops (the op's
     `pw <= roi_pooled_width` mask is false everywhere, kernel.cu:107); an h of exactly 0 makes the ratio
     infinite -- the reference's `math.ceil` raises there, and so does this module.  A maximal ratio
     <= 0 (every w = 0) would make the reference's pooled width 0 (and its launch fail); it is 1 here.
@@ -77,9 +80,17 @@ class GroundTruthRRoiAlign(Module):
             m = height_jitter.numel()
             if per_image_jitter is None:
                 # the length tells only when it cannot be read both ways
+                # (rounds 1-3 read a length-n jitter per box; a ValueError here broke callers on exactly the
+                # batches where the counts coincide -- e.g. 8 boxes in an 8-image batch.  The per-box reading stays the
+                # default, with ONE warning per process.)
                 if m == n and batch_index is not None and m == features.shape[0] and n > 1:
-                    raise ValueError("height_jitter has one entry per box AND one per image (%d): say which with "
-                                     "per_image_jitter=True / False" % m)
+                    global _warned_ambiguous_jitter
+                    if not _warned_ambiguous_jitter:
+                        _warned_ambiguous_jitter = True
+                        import warnings
+                        warnings.warn("GroundTruthRRoiAlign: height_jitter has one entry per box AND one per image (%d); "
+                                      "read per BOX -- pass per_image_jitter=True / False to say which is meant" % m,
+                                      stacklevel=2)
                 per_image_jitter = m != n
             if per_image_jitter:
                 if batch_index is None:

@@ -21,7 +21,8 @@ class _RRoiAlignOp(Function):
     # autograd casts the feature gradient back to the features' dtype.
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, features, rois, pooled_height, pooled_width, spatial_scale, channels_last_out=False):
+    def forward(ctx, features, rois, pooled_height, pooled_width, spatial_scale, channels_last_out=False,
+                trig=rroi_align.TRIG_DOUBLE):
         ctx.pooled_height = pooled_height
         ctx.pooled_width = pooled_width
         ctx.spatial_scale = spatial_scale
@@ -29,9 +30,10 @@ class _RRoiAlignOp(Function):
         # a channels_last backbone gets its gradient back in channels_last storage
         ctx.channels_last_grad = (features.dim() == 4 and not features.is_contiguous()
                                   and features.is_contiguous(memory_format=torch.channels_last))
+        ctx.trig = trig   # the backward recomputes the bin centres: with the forward's recipe
         ctx.save_for_backward(rois)
         return rroi_align.forward(features, rois, pooled_height, pooled_width, spatial_scale,
-                                  channels_last_out=channels_last_out)
+                                  channels_last_out=channels_last_out, trig=trig)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -41,14 +43,18 @@ class _RRoiAlignOp(Function):
         grad_input = None
         if ctx.needs_input_grad[0]:
             grad_input = rroi_align.backward(grad_output, rois, ctx.feature_size, ctx.spatial_scale,
-                                             channels_last_grad=ctx.channels_last_grad)
-        return grad_input, None, None, None, None, None
+                                             channels_last_grad=ctx.channels_last_grad, trig=ctx.trig)
+        return grad_input, None, None, None, None, None, None
 
 
 class RRoiAlignFunction(object):
     """``RRoiAlignFunction(ph, pw, scale)(features, rois) -> (R, C, ph, pw)``."""
 
-    def __init__(self, pooled_height, pooled_width, spatial_scale, channels_last_out=False):
+    def __init__(self, pooled_height, pooled_width, spatial_scale, channels_last_out=False,
+                 trig=rroi_align.TRIG_DOUBLE):
+        # extension: the recipe of cos / sin of the ROI angle (kernel.cu:73-74) for this object's calls, forward and
+        # backward alike: TRIG_DOUBLE (the oracle's) or TRIG_FP32 (the reference's sources built for this GPU)
+        self.trig = int(trig)
         self.pooled_width = pooled_width
         self.pooled_height = pooled_height
         self.spatial_scale = spatial_scale
@@ -61,17 +67,17 @@ class RRoiAlignFunction(object):
         self.feature_size = features.size()
         self.rois = rois
         return _RRoiAlignOp.apply(features, rois, int(self.pooled_height), int(self.pooled_width),
-                                  float(self.spatial_scale), self.channels_last_out)
+                                  float(self.spatial_scale), self.channels_last_out, self.trig)
 
     # the legacy Function's two methods, callable by hand as in torch 0.4
     def forward(self, features, rois):
         self.feature_size = features.size()
         self.rois = rois
         return rroi_align.forward(features, rois, int(self.pooled_height), int(self.pooled_width),
-                                  float(self.spatial_scale), channels_last_out=self.channels_last_out)
+                                  float(self.spatial_scale), channels_last_out=self.channels_last_out, trig=self.trig)
 
     def backward(self, grad_output):
         assert self.feature_size is not None and grad_output.is_cuda
         grad_input = rroi_align.backward(grad_output, self.rois, self.feature_size,
-                                         float(self.spatial_scale))
+                                         float(self.spatial_scale), trig=self.trig)
         return grad_input, None

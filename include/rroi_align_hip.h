@@ -53,15 +53,16 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
                              float* bottom_diff, const float* con_idx_x, const float* con_idx_y,
                              void* stream);
 
-/* The two launchers above carry no workspace argument: the library keeps one scratch buffer per
- * (device, stream), grown on demand and reused by later calls on that stream (no allocation per call;
- * a call whose buffer exists only enqueues kernels and can be captured into a HIP graph).
- * Lifetime: a buffer handed out while its stream was CAPTURING is part of a graph and is never freed
- * afterwards -- a later, larger call on that stream takes stream-ordered memory for itself, the
- * least-recently-used eviction (16 buffers are kept) passes it over, and the function below leaves it
- * alone -- so a captured launcher call stays replayable for the life of the process.  To capture with
- * memory the GRAPH owns instead, capture the first call on a stream that has no buffer yet (or one
- * that is too small): that call allocates inside the capture.
+/* The two launchers above carry no workspace argument: the library keeps one scratch buffer per (device, stream),
+ * grown on demand and reused by later calls on that stream (no allocation per call; a call whose buffer exists only
+ * enqueues kernels and can be captured into a HIP graph).  Calls on different streams do not serialise each other.
+ * Lifetime: a buffer handed out while its stream was CAPTURING is part of that graph and from then on GRAPH-EXCLUSIVE:
+ * never freed afterwards, never handed out again -- later eager calls on the stream get a buffer of their own, later
+ * captures take stream-ordered memory their own graph owns -- so a captured launcher call stays replayable for the
+ * life of the process, on any stream, concurrently with eager calls (replays of ONE graph must of course be ordered
+ * among themselves, as for any graph that writes its own scratch).  To capture with memory the GRAPH owns from the
+ * start, capture the first call on a stream that has no buffer yet (or one that is too small): that call allocates
+ * inside the capture.
  * This frees every buffer no graph holds (synchronously); they are re-created on demand.
  * Returns 1 / -hipError. */
 int rroi_align_release_launcher_scratch(void);
@@ -98,6 +99,21 @@ int rroi_align_release_launcher_scratch(void);
                                     exceeded) AND its own rule holds: at most two channel chunks per
                                     lane, or four with <= 8 bins per map pixel, or eight with <= 1, and
                                     R x B <= 8192.  Named, it runs wherever its 32-bit offsets hold   */
+
+/* path flags (OR into `path`; round 5).
+ * RROI_PATH_TRIG_FP32: the one library-dependent step of the arithmetic (rroi_align_kernel.cu:73-74, `cos(angle)` /
+ * `sin(angle)` of a float) for THIS call.  Default (bit clear) = RROI_TRIG_DOUBLE: (float)cos((double)angle), the
+ * recipe of the oracle -- bit-exact against it and against the reference's sources evaluated with a correctly rounded
+ * cosine.  Bit set = RROI_TRIG_FP32: cosf / sinf of the device library, what the reference's own sources call when they
+ * are built for this GPU -- bit-exact, every bin, against that build (oracle/_ref/librroi_ref_hip_nofma.so).  The two
+ * differ in 15-17 bins per million, at rounding ties.  The recipe is a kernel argument: stream-ordered, capturable
+ * into a HIP graph, independent per call -- pass the SAME bit to the backward of a forward (the Python surface keeps
+ * it in the autograd context).  Rounds 3-4 had a per-device setter (rroi_align_set_trig_recipe_hip): removed in 0.7.0.
+ * The reference-ABI launchers of section 1 have no `path`: they use RROI_TRIG_DOUBLE, or RROI_TRIG_FP32 when the
+ * process was started with RROI_ALIGN_LAUNCHER_TRIG=fp32 in its environment (read once, at the first launcher call). */
+#define RROI_PATH_TRIG_FP32 0x100
+#define RROI_TRIG_DOUBLE 0
+#define RROI_TRIG_FP32 1
 
 /* Bytes of scratch the tiled path needs for this problem (0 for the direct
  * path).  The caller owns the scratch; its contents are dead after the call. */
@@ -205,6 +221,11 @@ int rroi_align_gt_quads_to_rois_hip(const float* quads, const float* batch_index
  *        records in host memory -> boxes (n, 9) fp32 [x0,y0,..,x3,y3 in px, score]; returns the
  *        number of boxes found (writes at most max_boxes), or -1 on an invalid argument.
  * ------------------------------------------------------------------------- */
+/* Format of the 64-byte candidate record: 1 = {quad[8], score, probs[4], x, y, pad} (versions <= 0.5),
+ * 2 = {quad[8], score, rdist[4], x, y, pad} (0.6.0 on: raw distances, confidences formed by rroi_nms_merge_host).
+ * A consumer that reads records itself checks this constant against the library's rroi_nms_record_format(). */
+#define RROI_NMS_RECORD_FORMAT 2
+int rroi_nms_record_format(void);
 int rroi_rbox_decode_hip(const float* segm, const float* rbox, const float* angle, int height, int width,
                          float segm_thresh, void* candidates, int capacity, int* count, void* stream);
 int rroi_nms_merge_host(const void* candidates, int num_candidates, int width, int height, float iou_threshold,
@@ -229,6 +250,10 @@ int rroi_ctc_greedy_decode_hip(const float* logits, int num_seqs, int num_classe
 int rroi_align_bin_centres_hip(float spatial_scale, int num_rois, int height, int width,
                                int pooled_height, int pooled_width, const float* rois,
                                float* geom, void* stream);
+/* ... with the trig recipe stated (RROI_TRIG_DOUBLE / RROI_TRIG_FP32; the function above = RROI_TRIG_DOUBLE). */
+int rroi_align_bin_centres_trig_hip(float spatial_scale, int num_rois, int height, int width,
+                                    int pooled_height, int pooled_width, const float* rois,
+                                    float* geom, int trig_recipe, void* stream);
 
 /* (float)cos((double)x), (float)sin((double)x) of n angles given in degrees,
  * through the same device code the kernels use (test hook for the one
@@ -240,20 +265,7 @@ int rroi_align_sincos_probe_hip(const float* angle_deg, int n, float* out, void*
  * a write of non-zero, non-constant data reaches on the box (zeros are written faster on this chip). */
 int rroi_align_write_probe_hip(float* out, size_t num_floats, void* stream);
 
-/* The one library-dependent step of the arithmetic (rroi_align_kernel.cu:73-74, `cos(angle)` / `sin(angle)` of a
- * float).  RROI_TRIG_DOUBLE (default): (float)cos((double)angle), the recipe of the oracle -- bit-exact against it
- * and against the reference's sources evaluated with a correctly rounded cosine.  RROI_TRIG_FP32: cosf / sinf of
- * the device library, what the reference's own sources call when they are built for this GPU -- bit-exact, every
- * bin, against that build (oracle/_ref/librroi_ref_hip_nofma.so).  The two differ in 15-17 bins per million, at
- * rounding ties.  The setting is PER DEVICE (the current one), applies to every entry point that derives an affine
- * from ROIs (forward, backward, bin centres, the reference-ABI launchers), and the setter synchronises with the
- * device.  set: 1 ok / 0 invalid recipe / -hipError; get: the recipe, or -hipError. */
-#define RROI_TRIG_DOUBLE 0
-#define RROI_TRIG_FP32 1
-int rroi_align_set_trig_recipe_hip(int recipe);
-int rroi_align_get_trig_recipe_hip(void);
-
-/* Identification: "rroi_align_hip <version> gfx950". */
+/* Identification: "rroi_align_hip <version> gfx950" (0.7.0: per-call trig recipe, device-wide setter removed). */
 const char* rroi_align_hip_version(void);
 
 #ifdef __cplusplus

@@ -141,19 +141,21 @@ def test_python_constants_are_the_headers():
     import re
     from rroi_align._ext import rroi_align as ext
     text = open(os.path.join(ROOT, "include", "rroi_align_hip.h")).read()
-    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+RROI_((?:PATH|LAYOUT|TRIG)_\w+)\s+(\d+)", text)}
-    assert len(defs) >= 11 and "TRIG_FP32" in defs
+    defs = {m.group(1): int(m.group(2), 0)
+            for m in re.finditer(r"#define\s+RROI_((?:PATH|LAYOUT|TRIG)_\w+)\s+(0x[0-9a-fA-F]+|\d+)", text)}
+    assert len(defs) >= 12 and "TRIG_FP32" in defs and defs["PATH_TRIG_FP32"] == 0x100
     for name, value in defs.items():
         assert getattr(ext, name) == value, name
-    assert set(ext.BACKWARD_PATHS) == {v for k, v in defs.items() if k.startswith("PATH_")}
+    # path values live in the low byte, flags above it
+    assert set(ext.BACKWARD_PATHS) == {v for k, v in defs.items() if k.startswith("PATH_") and v < 0x100}
     assert set(ext.FORWARD_PATHS) <= set(ext.BACKWARD_PATHS)
 
 
 @pytest.mark.gpu
 def test_write_probe_and_trig_recipe_hooks():
     """Round-4 entry points: the bench's write probe fills exactly the floats it is given (values that differ from
-    store to store, nothing behind them), refuses misaligned / odd requests; the trig recipe is per-device state that
-    the setter returns and validates."""
+    store to store, nothing behind them), refuses misaligned / odd requests.  Round 5: the trig recipe travels in the
+    call (`path | RROI_PATH_TRIG_FP32`), the device-wide setter is gone."""
     import torch
     from rroi_align._ext import rroi_align as ext
     buf = torch.full((4096 + 8,), float("nan"), device="cuda")
@@ -164,8 +166,25 @@ def test_write_probe_and_trig_recipe_hooks():
     assert ext._lib.rroi_align_write_probe_hip(buf.data_ptr(), 4094, st) == 0       # not a multiple of 4 floats
     assert ext._lib.rroi_align_write_probe_hip(buf.data_ptr() + 4, 4096, st) == 0   # not 16-byte aligned
     assert ext._lib.rroi_align_write_probe_hip(buf.data_ptr(), 0, st) == 1
-    assert ext._lib.rroi_align_get_trig_recipe_hip() == ext.TRIG_DOUBLE
-    assert ext._lib.rroi_align_set_trig_recipe_hip(5) == 0 and ext._lib.rroi_align_get_trig_recipe_hip() == ext.TRIG_DOUBLE
-    assert ext.set_trig_recipe(ext.TRIG_FP32) == ext.TRIG_DOUBLE
-    assert ext._lib.rroi_align_get_trig_recipe_hip() == ext.TRIG_FP32
-    assert ext.set_trig_recipe(ext.TRIG_DOUBLE) == ext.TRIG_FP32
+    # round 5: the trig recipe is a flag bit of the call's `path` (no device-wide setter any more); unknown flag bits
+    # and unknown recipes are refused
+    for gone in ("rroi_align_set_trig_recipe_hip", "rroi_align_get_trig_recipe_hip"):
+        with pytest.raises(AttributeError):
+            getattr(ext._lib, gone)
+    F = torch.randn(1, 4, 16, 16, device="cuda")
+    R = torch.tensor([[0, 30, 30, 10, 40, 20.0]], device="cuda")
+    a = ext.forward(F, R, 4, 16, 0.25, trig=ext.TRIG_DOUBLE)
+    b = ext.forward(F, R, 4, 16, 0.25, trig=ext.TRIG_FP32)
+    assert a.shape == b.shape == (1, 4, 4, 16)
+    with pytest.raises(ValueError):
+        ext.forward(F, R, 4, 16, 0.25, trig=7)
+    out = torch.empty(1, 4, 4, 16, device="cuda")
+    for bad in (0x200, 0x1000 | ext.PATH_DIRECT):
+        assert ext._lib.rroi_align_forward_hip(F.data_ptr(), 0, 0.25, 1, 1, 16, 16, 4, 4, 16, R.data_ptr(), out.data_ptr(),
+                                               None, 0, bad, st) == 0
+    assert ext._lib.rroi_align_forward_hip(F.data_ptr(), 0, 0.25, 1, 1, 16, 16, 4, 4, 16, R.data_ptr(), out.data_ptr(),
+                                           None, 0, ext.PATH_DIRECT | ext.PATH_TRIG_FP32, st) == 1
+    assert torch.equal(out, ext.forward(F, R, 4, 16, 0.25, path=ext.PATH_DIRECT, trig=ext.TRIG_FP32))
+    geom = torch.empty(1, 4, 16, 2, device="cuda")
+    assert ext._lib.rroi_align_bin_centres_trig_hip(0.25, 1, 16, 16, 4, 16, R.data_ptr(), geom.data_ptr(), 5, st) == 0
+    assert ext._lib.rroi_nms_record_format() == 2

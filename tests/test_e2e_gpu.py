@@ -36,7 +36,8 @@ def test_backbone_on_gpu_matches_the_reference_fixture(setup):
 
 @pytest.mark.parametrize("size,nbox", [((256, 384), 9), ((704, 1280), 24)])
 def test_batched_recognition_equals_the_per_word_loop(setup, size, nbox):
-    from fots_e2e.pipeline import batched, synthetic_boxes
+    from e2e_inputs import synthetic_boxes
+    from fots_e2e.pipeline import batched
     from oracle.e2e_loop_oracle import per_box
     net, conv, dev = setup
     torch.manual_seed(3)
@@ -67,7 +68,8 @@ def test_batched_recognition_equals_the_per_word_loop(setup, size, nbox):
 
 def test_batched_recognition_edge_cases(setup):
     """no box at all; one box; boxes that all fall into one pooled-width bucket"""
-    from fots_e2e.pipeline import batched, synthetic_boxes
+    from e2e_inputs import synthetic_boxes
+    from fots_e2e.pipeline import batched
     from oracle.e2e_loop_oracle import per_box
     net, conv, dev = setup
     torch.manual_seed(4)
@@ -90,7 +92,7 @@ def test_bench_e2e_measure_runs(setup):
 
 
 def _detector_hook(size, nwords, seed, dev):
-    from fots_e2e.pipeline import synthetic_detector_maps
+    from e2e_inputs import synthetic_detector_maps
     maps = tuple(torch.from_numpy(a).to(dev) for a in synthetic_detector_maps(size[0], size[1], nwords, seed=seed))
     return lambda im_data: maps
 

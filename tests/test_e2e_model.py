@@ -10,7 +10,8 @@ import torch
 
 from fots_e2e.alphabet import ALPHABET
 from fots_e2e.model import FOTSNet
-from fots_e2e.pipeline import resize_rule, synthetic_boxes, target_widths_host
+from e2e_inputs import synthetic_boxes
+from fots_e2e.pipeline import resize_rule, target_widths_host
 from oracle.e2e_loop_oracle import host_roi
 from fots_e2e.weights import deterministic_init
 

@@ -67,7 +67,8 @@ def test_cfg3_forward_backward(ext, oracle, full):
     gwant = oracle.backward_c((2 * want).astype(np.float32), r, f.shape, 0.25)
     got = feats.grad.cpu().numpy()
     scale = float(np.abs(gwant).max())
-    assert np.abs(got - gwant).max() <= 1e-4 * scale, (np.abs(got - gwant).max(), scale)
+    # BASELINE configs[2]: "parity <= 1e-4" -- max-abs, not relative
+    Wk.check_backward(got, gwant, "cfg3 through autograd", require_abs=True)
     # backward is linear in grad_output
     g1 = ext.backward(pooled.detach() * 2, rois, f.shape, 0.25)
     g2 = ext.backward(pooled.detach() * 4, rois, f.shape, 0.25)

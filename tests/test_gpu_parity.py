@@ -150,8 +150,11 @@ def test_backward_vs_oracle(ext, oracle, name, path):
          "tiled_inkernel": ext.PATH_TILED_INKERNEL, "tiled_atomic": ext.PATH_TILED_ATOMIC,
          "tiled_buckets": ext.PATH_TILED_BUCKETS}[path]
     got = ext.backward(dev(gout), dev(r), f.shape, s, path=p).cpu().numpy()
-    scale = max(1.0, float(np.abs(want).max()))
-    assert np.abs(got - want).max() <= BWD_RTOL * scale
+    # max-abs <= 1e-4 (BASELINE configs[2]) -- except c5_pad, the heavy-overlap case of this list: 17 ROIs of 32 x 57
+    # bins on a 64 x 64 map put hundreds of terms on a pixel, max |grad| = 250, where ONE fp32 ulp is 3e-5 and the
+    # order of the sum alone moves the result by 1e-4 (measured 0.8 - 1.1e-4 = 4e-7 of the scale on every path, the
+    # reference's unordered atomicAdds included): relative bar there
+    Wk.check_backward(got, want, f"{name} {path}", require_abs=name != "c5_pad")
     assert eq(got == 0, want == 0) or np.abs(got[(got == 0) != (want == 0)]).max() < 1e-30
 
 

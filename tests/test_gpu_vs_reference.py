@@ -153,12 +153,12 @@ def test_cos_sin_recipe_drift_budget_against_the_reference_build(ref):
 
 
 def test_ocml_trig_recipe_moves_no_bin(ref):
-    """the opt-in fp32 recipe (ext.set_trig_recipe(ext.TRIG_FP32): cosf / sinf of the device
-    library, as the reference's sources call them, kernel.cu:73-74) against the reference's own kernels built for
-    this GPU: >= 33 M bins over all angles, a quarter of the ROIs on rounding ties (the mix on which the default
-    recipe moves 16.8 bins per million) -- NO bin's sample point moves, no output element differs, on either
-    forward path; con_idx through the reference-ABI entry point identical too.  The default recipe (and with it the
-    oracle parity of every other test) is restored afterwards."""
+    """the opt-in fp32 recipe (`trig=ext.TRIG_FP32`, PER CALL since round 5: cosf / sinf of
+    the device library, as the reference's sources call them, kernel.cu:73-74) against the reference's own kernels
+    built for this GPU: >= 33 M bins over all angles, a quarter of the ROIs on rounding ties (the mix on which the
+    default recipe moves 16.8 bins per million) -- NO bin's sample point moves, no output element differs, on either
+    forward path.  Nothing is switched device-wide: calls with the default recipe in between stay bit-exact against
+    the oracle (the last assertion)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
         "fuzz_ref", os.path.join(os.path.dirname(REFDIR), "..", "tools", "fuzz_ref.py"))
@@ -168,40 +168,159 @@ def test_ocml_trig_recipe_moves_no_bin(ref):
     rng = np.random.default_rng(11)          # the seed of profiles/r03_fuzz_ref.json
     ph, pw, s, H, W = 8, 64, 0.25, 160, 160
     F = torch.from_numpy(rng.standard_normal((1, 1, H, W), dtype=np.float32)).cuda()
-    old = ext.set_trig_recipe(ext.TRIG_FP32)
-    try:
-        assert old == ext.TRIG_DOUBLE
-        bins = moved = differ = 0
-        for rnd in range(16):
-            r = fz.random_rois(rng, 4096)
-            R = torch.from_numpy(r).cuda()
-            want, ix, iy = ref_forward(ref, F, R, ph, pw, s)
-            geom = ext.bin_centres(R, ph, pw, s, H, W)
-            moved += int(((geom[..., 0] != ix[:, 0]) | (geom[..., 1] != iy[:, 0])).sum())
-            for path in (ext.PATH_TILED, ext.PATH_DIRECT):
-                got = ext.forward(F, R, ph, pw, s, path=path)
-                differ += int((~((got == want) | (got.isnan() & want.isnan()))).sum())
-            bins += geom[..., 0].numel()
-            if rnd == 0:   # the reference-ABI entry point of this library, con_idx included
-                out2, ix2, iy2 = (torch.empty_like(want) for _ in range(3))
-                assert ext.rroi_align_forward_cuda(ph, pw, s, F, R, out2, ix2, iy2) == 1
-                assert torch.equal(ix2, ix) and torch.equal(iy2, iy)
-                assert bool(((out2 == want) | (out2.isnan() & want.isnan())).all())
-        assert bins >= 33_000_000
-        assert moved == 0 and differ == 0, (moved, differ, bins)
-        # training-like pooled shape (11 x 83: the SHIFT kernels), several images, through the backward as well
-        f, r = Wk.bench_inputs(R=400, C=64, H=120, W=160, img=640, seed=8, batch=2)
-        F2, R2 = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
-        want, ix, iy = ref_forward(ref, F2, R2, 11, 83, 0.25)
-        assert torch.equal(ext.forward(F2, R2, 11, 83, 0.25), want)
-        gout = torch.randn_like(want)
-        gwant = torch.zeros_like(F2)
-        ref.RROIAlignBackwardLaucher(gout.data_ptr(), 0.25, 2, 400, 120, 160, 64, 11, 83, R2.data_ptr(), gwant.data_ptr(),
-                                     ix.data_ptr(), iy.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        got = ext.backward(gout, R2, f.shape, 0.25)
-        assert float((got - gwant).abs().max()) <= 1e-4 * float(gwant.abs().max())
-    finally:
-        ext.set_trig_recipe(old)
-    assert ext.set_trig_recipe(ext.TRIG_DOUBLE) == ext.TRIG_DOUBLE
-    with pytest.raises(ValueError):
-        ext.set_trig_recipe(7)
+    T = ext.TRIG_FP32
+    bins = moved = differ = moved_default = 0
+    for rnd in range(16):
+        r = fz.random_rois(rng, 4096)
+        R = torch.from_numpy(r).cuda()
+        want, ix, iy = ref_forward(ref, F, R, ph, pw, s)
+        geom = ext.bin_centres(R, ph, pw, s, H, W, trig=T)
+        moved += int(((geom[..., 0] != ix[:, 0]) | (geom[..., 1] != iy[:, 0])).sum())
+        g0 = ext.bin_centres(R, ph, pw, s, H, W)
+        moved_default += int(((g0[..., 0] != ix[:, 0]) | (g0[..., 1] != iy[:, 0])).sum())
+        for path in (ext.PATH_TILED, ext.PATH_DIRECT):
+            got = ext.forward(F, R, ph, pw, s, path=path, trig=T)
+            differ += int((~((got == want) | (got.isnan() & want.isnan()))).sum())
+        bins += geom[..., 0].numel()
+    assert bins >= 33_000_000
+    assert moved == 0 and differ == 0, (moved, differ, bins)
+    assert 0 < moved_default <= 50e-6 * bins      # the default recipe, interleaved with the fp32 calls: its own result
+    # training-like pooled shape (11 x 83: the SHIFT kernels), several images, through the backward as well
+    f, r = Wk.bench_inputs(R=400, C=64, H=120, W=160, img=640, seed=8, batch=2)
+    F2, R2 = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
+    want, ix, iy = ref_forward(ref, F2, R2, 11, 83, 0.25)
+    assert torch.equal(ext.forward(F2, R2, 11, 83, 0.25, trig=T), want)
+    gout = torch.randn_like(want)
+    gwant = torch.zeros_like(F2)
+    ref.RROIAlignBackwardLaucher(gout.data_ptr(), 0.25, 2, 400, 120, 160, 64, 11, 83, R2.data_ptr(), gwant.data_ptr(),
+                                 ix.data_ptr(), iy.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    got = ext.backward(gout, R2, f.shape, 0.25, trig=T)
+    assert float((got - gwant).abs().max()) <= 1e-4 * float(gwant.abs().max())
+
+
+def test_trig_recipe_is_per_call(ref):
+    """the recipe is carried by the call.  Two streams run the two recipes CONCURRENTLY on the
+    same ROIs (a tie-heavy draw on which the recipes give different sample points) and each gets its own bit-exact
+    result -- TRIG_DOUBLE the oracle's, TRIG_FP32 the reference build's; forward + backward are capturable with
+    either recipe and a replay reproduces it; the autograd surface hands the forward's recipe to its backward."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_ref", os.path.join(os.path.dirname(REFDIR), "..", "tools", "fuzz_ref.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from oracle import rroi_align_oracle as O
+    from rroi_align._ext import rroi_align as ext
+    from rroi_align.modules.rroi_align import _RRoiAlign
+    rng = np.random.default_rng(11)
+    ph, pw, s, H, W, C = 8, 64, 0.25, 160, 160, 8
+    f = rng.standard_normal((1, C, H, W), dtype=np.float32)
+    r = fz.random_rois(rng, 4096)
+    F, R = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
+    g_d, g_f = ext.bin_centres(R, ph, pw, s, H, W), ext.bin_centres(R, ph, pw, s, H, W, trig=ext.TRIG_FP32)
+    assert int((g_d != g_f).any(-1).sum()) > 0, "the draw does not separate the recipes"
+    want_f, _, _ = ref_forward(ref, F, R, ph, pw, s)
+    want_d = torch.from_numpy(O.forward_c(f, r, ph, pw, s)).cuda()
+    assert not torch.equal(want_f, want_d)
+    sd, sf = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = {}
+    for rep in range(6):      # interleaved launches on two streams: the kernels of the two recipes overlap
+        for name, st_, trig in (("d", sd, ext.TRIG_DOUBLE), ("f", sf, ext.TRIG_FP32)):
+            with torch.cuda.stream(st_):
+                for path in (ext.PATH_TILED, ext.PATH_DIRECT):
+                    outs[name, path, rep] = ext.forward(F, R, ph, pw, s, path=path, trig=trig)
+    torch.cuda.synchronize()
+    for (name, path, rep), got in outs.items():
+        want = want_d if name == "d" else want_f
+        assert bool(((got == want) | (got.isnan() & want.isnan())).all()), (name, path, rep)
+    del outs
+    # graph capture with either recipe (native entry points, caller's workspace)
+    n = 256
+    Rn, B = R[:n].contiguous(), 1
+    out = torch.empty((n, C, ph, pw), device="cuda")
+    gin = torch.empty(f.shape, device="cuda")
+    nf = ext._lib.rroi_align_forward_workspace_bytes(B, C, H, W, n, 0)
+    nb = ext._lib.rroi_align_backward_workspace_bytes(B, C, H, W, n, ph, pw)
+    wf, wb = torch.empty(nf, dtype=torch.uint8, device="cuda"), torch.empty(nb, dtype=torch.uint8, device="cuda")
+    for trig, want in ((ext.TRIG_DOUBLE, want_d), (ext.TRIG_FP32, want_f)):
+        word = ext.PATH_TILED | (ext.PATH_TRIG_FP32 if trig else 0)
+
+        def calls():
+            st_ = torch.cuda.current_stream().cuda_stream
+            assert ext._lib.rroi_align_forward_hip(F.data_ptr(), 0, s, B, n, H, W, C, ph, pw, Rn.data_ptr(),
+                                                   out.data_ptr(), wf.data_ptr(), nf, word, st_) == 1
+            assert ext._lib.rroi_align_backward_hip(out.data_ptr(), s, B, n, H, W, C, ph, pw, Rn.data_ptr(),
+                                                    gin.data_ptr(), wb.data_ptr(), nb, word, st_) == 1
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            calls()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gin_eager = gin.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            calls()
+        out.zero_()
+        gin.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert bool(((out == want[:n]) | (out.isnan() & want[:n].isnan())).all()), trig
+        assert float((gin - gin_eager).abs().max()) <= 1e-4 * max(1.0, float(gin_eager.abs().max()))
+    # autograd: the backward of a TRIG_FP32 forward recomputes the bin centres with TRIG_FP32
+    Fg = F.clone().requires_grad_(True)
+    y = _RRoiAlign(ph, pw, s, trig=ext.TRIG_FP32)(Fg, Rn)
+    assert bool(((y == want_f[:n]) | (y.isnan() & want_f[:n].isnan())).all())
+    gout = torch.randn_like(y)
+    y.backward(gout)
+    g_f32 = ext.backward(gout, Rn, f.shape, s, trig=ext.TRIG_FP32)
+    g_dbl = ext.backward(gout, Rn, f.shape, s, trig=ext.TRIG_DOUBLE)
+    scale = max(1.0, float(g_f32.abs().max()))
+    assert float((Fg.grad - g_f32).abs().max()) <= 1e-5 * scale
+    # (where the recipes place a bin half a pixel apart the two gradients differ by whole tap weights)
+    if int((g_d[:n] != g_f[:n]).any(-1).sum()) > 0:
+        assert float((g_dbl - g_f32).abs().max()) > 1e-3
+
+
+def test_launcher_trig_environment(ref):
+    """The reference-ABI launchers carry no `path`: RROI_ALIGN_LAUNCHER_TRIG=fp32 in the environment of the process
+    (read once) makes them evaluate the device library's cosf / sinf, and then con_idx_x / con_idx_y and the crops
+    equal the reference build's in EVERY bin of a tie-heavy draw; without it they are the default recipe's.  Run in
+    a subprocess: the setting is a constant of the process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(REFDIR))
+    code = r'''
+import ctypes, os, sys, importlib.util
+import numpy as np, torch
+root = sys.argv[1]
+sys.path[:0] = [root, os.path.join(root, "fots.pytorch_amd"), os.path.join(root, "tests")]
+from rroi_align._ext import rroi_align as ext
+spec = importlib.util.spec_from_file_location("fuzz_ref", os.path.join(root, "tools", "fuzz_ref.py"))
+fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+ref = fz.load_ref()
+rng = np.random.default_rng(11)
+F = torch.from_numpy(rng.standard_normal((1, 2, 160, 160), dtype=np.float32)).cuda()
+moved = 0
+for n in (4096, 12):     # the tiled launcher path and the direct one
+    R = torch.from_numpy(fz.random_rois(rng, n)).cuda()
+    want, ix, iy = (torch.zeros((n, 2, 8, 64), device="cuda") for _ in range(3))
+    ref.RROIAlignForwardLaucher(F.data_ptr(), 0.25, n, 160, 160, 2, 8, 64, R.data_ptr(), want.data_ptr(), ix.data_ptr(),
+                                iy.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    out, ox, oy = (torch.empty_like(want) for _ in range(3))
+    assert ext.rroi_align_forward_cuda(8, 64, 0.25, F, R, out, ox, oy) == 1
+    moved += int(((ox != ix) | (oy != iy)).sum())
+    if os.environ.get("RROI_ALIGN_LAUNCHER_TRIG") == "fp32":
+        assert bool(((out == want) | (out.isnan() & want.isnan())).all())
+print("MOVED", moved)
+'''
+    res = {}
+    for mode in ("fp32", ""):
+        env = dict(os.environ)
+        env.pop("RROI_ALIGN_LAUNCHER_TRIG", None)
+        if mode:
+            env["RROI_ALIGN_LAUNCHER_TRIG"] = mode
+        p = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[mode] = int(p.stdout.strip().split("MOVED")[-1])
+    assert res["fp32"] == 0 and res[""] > 0, res

@@ -147,17 +147,20 @@ def test_ground_truth_module_and_degenerate_jitter(oracle):
     assert np.array_equal(rois2.cpu().numpy(), want2) and rois2.shape[0] == 32
     pw2 = RB.train_pooled_width(want2)
     assert np.array_equal(crops2.cpu().numpy(), oracle.forward_c(feats_np, want2, 11, pw2, 0.25, threads=8))
-    # as many boxes as images -- the length no longer decides silently.  Two boxes, both of image 1:
+    # as many boxes as images -- the length alone cannot decide: per box by default, with a warning.  Two boxes, both of image 1:
     # read per image the jitter of both is per_image[1], read per box it is per_image[0] and per_image[1]
     q2, b2 = q[[10, 11]], np.asarray([1.0, 1.0], np.float32)
     args = (feats, torch.from_numpy(q2).cuda(), torch.from_numpy(b2).cuda(), torch.from_numpy(per_image).cuda())
-    with pytest.raises(ValueError):
-        m(*args)
+    import rroi_align.batched as _B
+    _B._warned_ambiguous_jitter = False
+    with pytest.warns(UserWarning, match="per BOX"):     # the per-box default stays, with one warning
+        _, r_default = m(*args)
     _, r_img = m(*args, per_image_jitter=True)
     _, r_box = m(*args, per_image_jitter=False)
     assert np.array_equal(r_img.cpu().numpy(), RB.rois_from_quads(q2, b2, mode=1, jitter=per_image[[1, 1]])[0])
     assert np.array_equal(r_box.cpu().numpy(), RB.rois_from_quads(q2, b2, mode=1, jitter=per_image)[0])
     assert not np.array_equal(r_img.cpu().numpy(), r_box.cpu().numpy())
+    assert np.array_equal(r_default.cpu().numpy(), r_box.cpu().numpy())
 
 
 @pytest.mark.gpu

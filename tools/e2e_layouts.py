@@ -1,12 +1,13 @@
 """End-to-end pipeline: where the occasional 40-80 ms per-image stalls come from (debugging aid)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "fots.pytorch_amd")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "fots.pytorch_amd"), os.path.join(ROOT, "tests")]
 import torch
 from fots_e2e.alphabet import ALPHABET
 from bench_e2e import load_images
 from fots_e2e.model import FOTSNet
-from fots_e2e.pipeline import batched, preprocess, resize_rule, synthetic_boxes
+from fots_e2e.pipeline import batched, preprocess, resize_rule
+from e2e_inputs import synthetic_boxes
 from fots_e2e.weights import deterministic_init
 from rroi_align.decode import CTCLabelConverter
 

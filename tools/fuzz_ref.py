@@ -8,7 +8,7 @@ cosine is not correctly rounded, so over enough angles the two affines differ in
 for some ROIs, and where such a difference meets a rounding tie a bin's sample point moves.
 
     python tools/fuzz_ref.py [rois_per_round] [rounds] [seed]  ->  one JSON line
-    RROI_FUZZ_TRIG=fp32     the product's opt-in recipe (ext.set_trig_recipe(ext.TRIG_FP32)) for the campaign
+    RROI_FUZZ_TRIG=fp32     the product's opt-in recipe (trig=ext.TRIG_FP32 on every call) for the campaign
     RROI_FUZZ_POOLED=11x83  another pooled size
 
 Per round: `rois_per_round` random ROIs (every angle in [-180, 180), centres on and off the
@@ -61,7 +61,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 11)
     ref = load_ref()
     trig = os.environ.get("RROI_FUZZ_TRIG", "double")
-    ext.set_trig_recipe({"double": ext.TRIG_DOUBLE, "fp32": ext.TRIG_FP32}[trig])
+    T = {"double": ext.TRIG_DOUBLE, "fp32": ext.TRIG_FP32}[trig]   # per call (round 5)
     ph, pw, s, H, W = 8, 64, 0.25, 160, 160
     if os.environ.get("RROI_FUZZ_POOLED"):   # e.g. 11x83: rows that are not whole sectors (the SHIFT kernels)
         ph, pw = (int(v) for v in os.environ["RROI_FUZZ_POOLED"].split("x"))
@@ -76,7 +76,7 @@ def main():
         want, ix, iy = (torch.zeros((n, 1, ph, pw), device="cuda") for _ in range(3))
         ref.RROIAlignForwardLaucher(F.data_ptr(), s, n, H, W, 1, ph, pw, R.data_ptr(), want.data_ptr(),
                                     ix.data_ptr(), iy.data_ptr(), stream)
-        geom = ext.bin_centres(R, ph, pw, s, H, W)
+        geom = ext.bin_centres(R, ph, pw, s, H, W, trig=T)
         dxy = (geom[..., 0] != ix[:, 0]) | (geom[..., 1] != iy[:, 0])
         shift = torch.maximum((geom[..., 0] - ix[:, 0]).abs(), (geom[..., 1] - iy[:, 0]).abs())
         tot["rois"] += n
@@ -86,7 +86,7 @@ def main():
         tot["rois_centre_differs"] += int(per_roi.sum())
         tot["max_centre_shift"] = max(tot["max_centre_shift"], float(shift.max()))
         for name, path in (("tiled", ext.PATH_TILED), ("direct", ext.PATH_DIRECT)):
-            got = ext.forward(F, R, ph, pw, s, path=path)
+            got = ext.forward(F, R, ph, pw, s, path=path, trig=T)
             d = ~((got == want) | (got.isnan() & want.isnan()))
             tot["out_differs_" + name] += int(d.sum())
             if name == "tiled":
@@ -96,7 +96,6 @@ def main():
     tot["differing_bins_per_million"] = round(1e6 * tot["bins_centre_differs"] / max(1, tot["bins"]), 3)
     tot["pooled"] = [ph, pw]
     tot["trig_recipe"] = trig
-    ext.set_trig_recipe(ext.TRIG_DOUBLE)
     tot["example_rois"] = worst[:8]
     print(json.dumps(tot))
 

@@ -2,8 +2,7 @@
 // Measurement tooling (not product, not shipped): includes the product translation unit to
 // reuse its device code, adds ablation kernels, times everything with hipEvents.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -o tools/kbench tools/kbench.hip
-#define RROI_EXPLORE 1
-#include "../fots.pytorch_amd/csrc/rroi_align_hip.hip"
+#include "rroi_align_hip_explore.hip"
 
 #include <algorithm>
 #include <cstdio>

@@ -1,16 +1,10 @@
 // tools/rroi_explore_setters.h -- the rroi_align_debug_set_* knobs of the EXPLORATION build of the library.
-// Included by fots.pytorch_amd/csrc/rroi_align_hip.hip inside its extern "C" block, only with -DRROI_EXPLORE
-// (tools/kbench.hip defines it; tools/build_explore.sh builds tools/_explore/librroi_align_hip_explore.so with it).
+// Included by tools/rroi_align_hip_explore.hip BEHIND the product translation unit (which it includes with a mutable
+// `Tuning`), inside an extern "C" block; tools/build_explore.sh builds tools/_explore/librroi_align_hip_explore.so.
 // They write the `Tuning` struct that the product reads as compile-time constants: the product library neither
 // contains nor exports any of this.  Every setter returns the previous value.
 #pragma once
 
-int rroi_align_debug_set_bwd_relayout_aux(int v)
-{
-    const int old = g_tune.bwd_relayout_aux;
-    g_tune.bwd_relayout_aux = v;
-    return old;
-}
 // workgroups per CU of the strided split kernel (0: leave)
 int rroi_align_debug_set_split_wgs_per_cu(int v)
 {
@@ -26,11 +20,6 @@ int rroi_align_debug_set_fwd_shift(int v, int wgs_per_cu, int)
     if (v >= 0) g_tune.fwd_shift = v;
     if (wgs_per_cu >= 0) g_tune.shift_wgs_per_cu = wgs_per_cu;
     return old;
-}
-// per-workgroup time stamps of rroi_fwd_split_kernel (tools/wg_trace.py): a device buffer of 8 words per workgroup, or NULL
-int rroi_align_debug_set_wg_trace(unsigned* device_buffer)
-{
-    return status_of(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace), &device_buffer, sizeof(device_buffer)));
 }
 int rroi_align_debug_set_bwd_tile_run(int v)
 {
@@ -56,7 +45,8 @@ int rroi_align_debug_set_bwd_buckets(int v)
     g_tune.bwd_buckets = v;
     return old;
 }
-// ablations of the gather: 1 = output stores dropped, 2 = every tap out of range, 256 = every workgroup's first item free
+// ablations of the gather: 1 = output stores dropped, 2 = every tap out of range (the free-first-item bit 256 and the
+// per-workgroup time stamps need tools/experiments/r04_wg_trace_instrumentation.patch)
 int rroi_align_debug_set_fwd_dbg(int v)
 {
     const int old = g_tune.fwd_dbg;
@@ -67,12 +57,6 @@ int rroi_align_debug_set_prologue_blocks(int v)
 {
     const int old = g_tune.prologue_blocks_per_cu;
     if (v >= 1 && v <= 64) g_tune.prologue_blocks_per_cu = v;
-    return old;
-}
-int rroi_align_debug_set_prologue_aux(int v)
-{
-    const int old = g_tune.prologue_aux;
-    g_tune.prologue_aux = v;
     return old;
 }
 int rroi_align_debug_set_row_pad(int v)
