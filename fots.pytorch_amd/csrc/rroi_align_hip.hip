@@ -92,6 +92,8 @@ struct Tuning {
     int shift_wgs_per_cu = 0;     // > 0 overrides the SHIFT kernels' workgroups per CU
     int fwd_dbg = 0;              // ablations: 1 = skip output stores, 2 = all taps out of range, 256 = free first item
     int prologue_blocks_per_cu = 3;
+    int fwd_groups = 1;           // XCD groups for nchunks in {1, 2} (round 5; XcdGroups in rroi_forward_kernels.h); 0: off
+    int fwd_groups_min_rois = 64; // ... from this many ROIs up
     int bwd_buckets = 1;          // one-pass pixel lists (round 3); 0: count / scan / fill as in rounds 1-2
     int bwd_tile_run = 2;         // the in-place NCHW gather: 2^v neighbouring key tiles per XCD turn
     int bwd_skip_dead = 1;        // the relayout of top_diff leaves out the bins that enter no list (round 4)
@@ -190,25 +192,47 @@ PatchMap make_patch_map(int pooled_height, int pooled_width)
 
 struct Workspace {
     Affine* aff;
+    int* sort_rank;    // XCD groups: the counting sort's scratch and ...
+    int* sort_order;   // ... its result, ROI index by sorted position (R ints each)
     float* cm;
     size_t cm_bytes;
     size_t bytes;
 };
 
-// [affine table | chunk-major copy (B, nchunks, HW+1, 32)]; the copy is absent when
+// XCD groups (XcdGroups, rroi_forward_kernels.h): G = 8 / nchunks groups per chunk for one or two chunks (C <= 64)
+// and enough ROIs; else one group, the mapping of rounds 1-4
+int forward_groups(int num_rois, int nchunks, size_t out_bytes)
+{
+    // measured (tools/groups_ab.py, profiles/r05_groups_ab.txt; us per call, one group / G groups): C = 64, two
+    // 120 x 160 maps, 11 x 96: R = 512 38.3 / 33.3, R = 128 19.0 / 15.2, R = 32 12.0 / 12.4 (the sort's block is the last of
+    // its launch to finish: few ROIs keep one group); C = 128 (G = 2, a 3.3 MB slice per XCD already): 33.4 / 33.5
+    // the same with the cheap sort (r05_groups_ab2.txt): R = 512 38.2 / 32.1 (11 x 83: 39.3 / 32.9, 11 x 100: 42.0 / 35.3), R = 64
+    // 14.3 / 12.7, R = 32 12.0 / 12.1; eight 160 x 160 maps, R = 512, 11 x 100: 57.3 / 47.3.  ROIs bunched in a third of
+    // one image: +0.5 us.  Crops beyond the 256 MB memory-side cache (R = 2048, 11 x 100, 577 MB): 260 / 289 -- the
+    // sorted order scatters the stores of a moment over the whole tensor: one group there.
+    if (!g_tune.fwd_groups || (nchunks != 1 && nchunks != 2)) return 1;
+    if (out_bytes > ((size_t)256 << 20)) return 1;
+    const int G = 8 / nchunks;
+    return num_rois >= g_tune.fwd_groups_min_rois ? G : 1;
+}
+
+// [affine table | sort rank | sort order | chunk-major copy (B, nchunks, HW+1, 32)]; the copy is absent when
 // channels-last features with C % 4 == 0 are consumed in place.
 Workspace carve(void* ws, int batch_size, int channels, int height, int width, int num_rois,
                 int layout)
 {
     Workspace w;
     const size_t aff_bytes = align_up((size_t)(num_rois > 0 ? num_rois : 1) * sizeof(Affine), 256);
+    const size_t sort_bytes = align_up((size_t)(num_rois > 0 ? num_rois : 1) * sizeof(int), 256);   // x 2: rank, order
     const size_t nchunks = (channels + kChunk - 1) / kChunk;
     w.cm_bytes = layout == RROI_LAYOUT_NHWC
                      ? 0
                      : align_up((size_t)batch_size * nchunks * ((size_t)height * row_pitch(width) + 1) * kLineBytes, 256);
     w.aff = reinterpret_cast<Affine*>(ws);
-    w.cm = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + aff_bytes);
-    w.bytes = aff_bytes + w.cm_bytes;
+    w.sort_rank = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + aff_bytes);
+    w.sort_order = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + aff_bytes + sort_bytes);
+    w.cm = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + aff_bytes + 2 * sort_bytes);
+    w.bytes = aff_bytes + 2 * sort_bytes + w.cm_bytes;
     return w;
 }
 
@@ -618,6 +642,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     const bool zero_copy = feature_layout == RROI_LAYOUT_NHWC;
     const float* map = zero_copy ? features : ws.cm;
     const int pitch = row_pitch(width);
+    const int groups = launcher_rest ? 1 : forward_groups(num_rois, nchunks, (size_t)num_rois * channels * NB * sizeof(float));
 
     // prologue: relayout + affine table in one launch
     if (stages & RROI_STAGE_PROLOGUE) {
@@ -625,6 +650,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         const int relayout_tiles = zero_copy ? 0 : ptiles * nchunks * batch_size;
         // ~3 resident blocks per CU, each streaming several tiles with the next tile prefetched
         int relayout_blocks = relayout_tiles;
+        if (groups > 1) relayout_blocks = (relayout_blocks + 7) / 8 * 8;   // whole XCD rounds (a block without a tile leaves)
         if (relayout_blocks > num_cus() * g_tune.prologue_blocks_per_cu) {
             relayout_blocks = num_cus() * g_tune.prologue_blocks_per_cu;
             long unit = nchunks;
@@ -635,12 +661,12 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         const int rest_blocks = launcher_rest ? num_rois : 0;
 #define RROI_LAUNCH_PRO(AUX)                                                                        \
     hipLaunchKernelGGL(rroi_prologue_kernel<AUX>,                                                     \
-                       dim3(relayout_blocks + aff_blocks + rest_blocks), dim3(256), 0,               \
+                       dim3(relayout_blocks + aff_blocks + (groups > 1 ? 1 : 0) + rest_blocks), dim3(256), 0, \
                        stream, features, ws.cm, channels, HW, width, pitch,                           \
                        make_fastdiv((unsigned)width), nchunks, ptiles, relayout_blocks,               \
                        relayout_tiles, batch_size, rois, num_rois, pooled_height,                     \
                        spatial_scale, trig, ws.aff, aff_blocks, launcher_rest ? top_data : (float*)nullptr, \
-                       pooled_width)
+                       pooled_width, groups, ws.sort_rank, ws.sort_order)
         RROI_LAUNCH_PRO(0);   // plain stores: the copy stays in the L2s that wrote it (write-through: 1.8 us faster alone, the step is not)
 #undef RROI_LAUNCH_PRO
         const int st = launch_status();
@@ -669,7 +695,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
 #define RROI_GATHER(...)                                                                                              \
     hipLaunchKernelGGL((rroi_fwd_split_kernel<__VA_ARGS__>), dim3(plan.grid), dim3(2 * kWave), 0, stream, map, ws.aff, \
                        top_data, num_rois, channels, height, width, pooled_width, NB, batch_size, nchunks, ntiles, lay, \
-                       dt, dp, plan.dbg)
+                       dt, dp, plan.dbg, XcdGroups{groups, ws.sort_order})
         switch (plan.kernel) {
         case FwdKernel::kStrided:       RROI_GATHER(true, 0, 6, 3, false, 0); break;   // 62-64 VGPRs, 12.1 KB of LDS: 12 per CU
         case FwdKernel::kChannelsLast:  RROI_GATHER(true, 2, 5, 2, true, 0); break;    // 91 VGPRs: 10 per CU

@@ -222,22 +222,121 @@ __device__ __forceinline__ void direct_bin(const float* __restrict__ feat, const
     }
 }
 
+// XCD GROUPS (round 5; C < 256).  Workgroup b runs on XCD b % 8 (observed; it only ever changes speed).  With nchunks = 8
+// chunk k lives on XCD k: the prologue's blocks of XCD k write slice k through that XCD's L2 and the gather's blocks of
+// XCD k read it there.  With FEWER chunks (the reference's own call: C = 64, two chunks) rounds 1-4 dealt chunk k to
+// the XCDs x % nchunks == k and every item to every one of them: a chunk's slices were written through 8 / nchunks L2s
+// and gathered from all of them -- each XCD's working set was the whole chunk of every image (4.9 MB at C = 64, two
+// 120 x 160 maps: more than an L2), fetched from the memory-side cache first.  Now the G = 8 / nchunks XCDs of a chunk
+// split the WORK spatially: group g = x / nchunks relays out the g-th G-quantile of the (image, map row) space and
+// gathers the g-th G-quantile of the ROIs sorted by (image, centre row) -- `order`, built by one block of the
+// prologue launch with a counting sort (rroi_sort_rois).  For ROIs spread evenly over the images the two quantiles
+// coincide: an XCD gathers what it relaid out, and its working set is 1 / G of a chunk.  For any other spread the
+// ROI quantiles keep the load balanced and only the first touch comes from farther away.
+struct XcdGroups {
+    int G;                        // groups per chunk: 8 / nchunks (the host: for one or two chunks and enough ROIs), else 1 (= rounds 1-4)
+    const int* order;             // G > 1: ROI index by sorted position
+};
+
+// Counting sort of the ROIs by key = (image, band of the centre's map row): one workgroup, LDS histogram (`hist`:
+// kSortBuckets + 1 words), ranks by LDS atomics -- the order INSIDE a bucket depends on the atomics' order, which only
+// ever changes which workgroup processes a ROI.  ROIs whose image index is not in [0, batch_size) sort last.
+// The block must not outlast the relayout blocks of its launch (the prologue at C = 64 is 5 us): a thread keeps the
+// keys and ranks of its first kSortRegs ROIs in registers (R <= 1024: no round trip through `rank`), the histogram has
+// 1024 buckets (4 per thread in the scan).
+constexpr int kSortBuckets = 1024;
+constexpr int kSortRegs = 4;
+__device__ __forceinline__ void rroi_sort_rois(unsigned* hist, const float* __restrict__ rois, int num_rois, int batch_size,
+                                               int height, float spatial_scale, int* __restrict__ rank, int* __restrict__ order)
+{
+    const int tid = threadIdx.x;
+    int bands = kSortBuckets / batch_size;           // row bands per image (>= 1 while batch_size <= kSortBuckets)
+    if (bands > height) bands = height;
+    if (bands < 1) bands = 1;
+    const bool by_image_only = bands * batch_size > kSortBuckets;   // more images than buckets
+    const int nb = (by_image_only ? kSortBuckets : bands * batch_size) + 1;   // + the invalid bucket
+    constexpr int kPer = (kSortBuckets + 1 + 255) / 256;   // buckets per thread in the scan
+    for (int i = tid; i < nb; i += 256) hist[i] = 0u;
+    auto key_of = [&](int n) -> int {
+        const float* r = rois + (size_t)n * 6;
+        const int b = f2i_sat(r[0]);
+        if (b < 0 || b >= batch_size) return nb - 1;
+        if (by_image_only) return b % (nb - 1);
+        const float y = r[2] * spatial_scale;                       // the centre's map row (NaN -> band 0, +-inf -> an end)
+        int band = f2i_sat((y / (float)height) * (float)bands);
+        band = band < 0 ? 0 : (band >= bands ? bands - 1 : band);
+        return b * bands + band;
+    };
+    int key[kSortRegs], rk[kSortRegs];
+#pragma unroll
+    for (int e = 0; e < kSortRegs; ++e) {
+        const int n = tid + e * 256;
+        key[e] = n < num_rois ? key_of(n) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kSortRegs; ++e)
+        if (tid + e * 256 < num_rois) rk[e] = (int)atomicAdd(&hist[key[e]], 1u);
+    for (int n = tid + kSortRegs * 256; n < num_rois; n += 256) rank[n] = (int)atomicAdd(&hist[key_of(n)], 1u);
+    __syncthreads();
+    // exclusive scan of the histogram: 256 threads x kPer consecutive buckets + a block scan of the partial sums
+    {
+        unsigned mine[kPer], sum = 0;
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) {
+            const int i = tid * kPer + e;
+            mine[e] = i < nb ? hist[i] : 0u;
+            sum += mine[e];
+        }
+        unsigned incl = sum;
+        const unsigned lane = tid & 63u, wv = tid >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d, 64);
+            if (lane >= (unsigned)d) incl += o;
+        }
+        __shared__ unsigned wsum[4];
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();     // (every hist[] value has been read into registers)
+        unsigned run = incl - sum + (wv > 0 ? wsum[0] : 0u) + (wv > 1 ? wsum[1] : 0u) + (wv > 2 ? wsum[2] : 0u);
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) {
+            const int i = tid * kPer + e;
+            if (i < nb) hist[i] = run;
+            run += mine[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kSortRegs; ++e)
+        if (tid + e * 256 < num_rois) order[hist[key[e]] + (unsigned)rk[e]] = tid + e * 256;
+    for (int n = tid + kSortRegs * 256; n < num_rois; n += 256) order[hist[key_of(n)] + (unsigned)rank[n]] = n;
+}
+
 template <int AUX>
 __global__ __launch_bounds__(256) void rroi_prologue_kernel(
     const float* __restrict__ nchw, float* __restrict__ cm, int C, int HW, int width, int pitch,
     FastDiv div_w, int nchunks, int ptiles, int relayout_blocks, int relayout_tiles,
     int batch_size, const float* __restrict__ rois, int num_rois, int pooled_height,
     float spatial_scale, int trig, Affine* __restrict__ aff, int aff_blocks = 0, float* __restrict__ rest_out = nullptr,
-    int pooled_width = 0)
+    int pooled_width = 0, int groups = 1, int* __restrict__ sort_rank = nullptr, int* __restrict__ sort_order = nullptr)
 {
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
+    static_assert(sizeof(T) >= (kSortBuckets + 1) * sizeof(unsigned), "the sort's histogram lives in the relayout tile");
     const int tid = threadIdx.x;
-    if (rest_out && (int)blockIdx.x >= relayout_blocks + aff_blocks) {
+    // block order: [relayout][affine table][ROI sort (groups > 1)][the launcher's rest-of-the-images blocks]
+    const int sort_blocks = groups > 1 ? 1 : 0;
+    if (sort_blocks && (int)blockIdx.x == relayout_blocks + aff_blocks) {
+        rroi_sort_rois(reinterpret_cast<unsigned*>(T), rois, num_rois, batch_size, HW / width, spatial_scale, sort_rank,
+                       sort_order);
+        return;
+    }
+    if (rest_out && (int)blockIdx.x >= relayout_blocks + aff_blocks + sort_blocks) {
         // The reference-ABI launcher (one more block per ROI).  Its signature does not say how many images
         // `nchw` holds, so the copy and the tiled gather serve image 0; the ROIs of images >= 1 -- none, as a
         // rule: the block reads the index and leaves -- are sampled here from the NCHW tensor, trusting the
         // index as the reference does, and the gather leaves their crops alone.
-        const int n = (int)blockIdx.x - relayout_blocks - aff_blocks;
+        const int n = (int)blockIdx.x - relayout_blocks - aff_blocks - sort_blocks;
         if (f2i_sat(rois[(size_t)n * 6]) < batch_size) return;
         const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale, trig);
         const int NB = pooled_height * pooled_width;
@@ -248,6 +347,17 @@ __global__ __launch_bounds__(256) void rroi_prologue_kernel(
     if ((int)blockIdx.x >= relayout_blocks) {
         const int n = ((int)blockIdx.x - relayout_blocks) * 256 + tid;
         if (n < num_rois) aff[n] = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale, trig);
+        return;
+    }
+    if (groups > 1) {
+        // XCD x = block % 8 serves chunk x % nchunks and the g-th quantile (g = x / nchunks) of the spatial tiles
+        // sp = image * ptiles + pixel tile; tile index = sp * nchunks + chunk (relayout_run decodes it)
+        const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3, per_xcd = relayout_blocks >> 3;
+        const int k = x % nchunks, g = x / nchunks;
+        const int SP = relayout_tiles / nchunks;
+        const int lo = (int)(((long)g * SP) / groups), hi = (int)(((long)(g + 1) * SP) / groups);
+        relayout_run<AUX, false>(T, nchw, cm, C, HW, width, pitch, div_w, nchunks, ptiles, (lo + j) * nchunks + k,
+                                   per_xcd * nchunks, hi * nchunks, nullptr, 0);
         return;
     }
     relayout_run<AUX, false>(T, nchw, cm, C, HW, width, pitch, div_w, nchunks, ptiles, (int)blockIdx.x,
@@ -311,7 +421,7 @@ template <bool VEC_STORE, int EARLY, int OCC, int HID, bool ONHWC, int SHIFT>
 __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
-    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg)
+    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg, XcdGroups xg)
 {
     // A tile's bins are processed in CLASS-SORTED groups of 8, because the texture addresser
     // charges 16 cycles for every dwordx4 wave instruction whatever the number of lanes that
@@ -348,14 +458,34 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     __shared__ __attribute__((aligned(16))) uint4 Gbuf[2 * kRecs];
     __shared__ unsigned char HPbuf[2 * kRecs];
     __shared__ uint4 shead[2];  // per record set: LO groups, HI groups, mask of the bins that are in a group
+    __shared__ int sbatch[2];   // ... and the item's image index (the gatherer takes it from here, not from memory)
 
     const unsigned lane = threadIdx.x & 63u;
     // wave 0 gathers (loads only), wave 1 streams the finished tiles out (stores only)
     const bool storer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1;
-    const unsigned k = blockIdx.x % (unsigned)nchunks;
-    const unsigned slot = blockIdx.x / (unsigned)nchunks;
-    const unsigned nslots = gridDim.x / (unsigned)nchunks;
-    const unsigned items = (unsigned)num_rois * (unsigned)ntiles;
+    // block -> (chunk, slot) and the ROIs the slot's items come from.  One group: chunk = block % nchunks, every
+    // (roi, tile) item of the call, dealt every nslots-th.  XCD groups (see XcdGroups): XCD x = block % 8 -> chunk
+    // x % nchunks, group g = x / nchunks, the items of the sorted ROIs [r0, r1) dealt to the XCD's gridDim / 8 blocks.
+    unsigned k, slot, nslots, r0 = 0u, r1 = (unsigned)num_rois;
+    if (xg.G > 1) {
+        const unsigned x = blockIdx.x & 7u, g = x / (unsigned)nchunks;
+        k = x % (unsigned)nchunks;
+        slot = blockIdx.x >> 3;
+        nslots = gridDim.x >> 3;
+        r0 = (unsigned)(((unsigned long long)g * (unsigned)num_rois) / (unsigned)xg.G);
+        r1 = (unsigned)(((unsigned long long)(g + 1u) * (unsigned)num_rois) / (unsigned)xg.G);
+    } else {
+        k = blockIdx.x % (unsigned)nchunks;
+        slot = blockIdx.x / (unsigned)nchunks;
+        nslots = gridDim.x / (unsigned)nchunks;
+    }
+    const unsigned items = (r1 - r0) * (unsigned)ntiles;
+    // item c of the slot's sequence -> ROI (through the sort's order where there is one) and tile
+    auto roi_of = [&](unsigned c, unsigned& t) -> unsigned {
+        const unsigned pos = fdiv(c, div_tiles);
+        t = c - pos * (unsigned)ntiles;
+        return xg.G > 1 ? (unsigned)xg.order[r0 + pos] : pos;
+    };
     const unsigned px_bytes = lay.px_bytes;
     const unsigned row_bytes = lay.row_bytes;
 
@@ -690,7 +820,8 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     unsigned cur = slot < items ? slot : kEnd;
     if (cur == kEnd) return;
     if (storer) {
-        unsigned n = fdiv(cur, div_tiles), t = cur - n * (unsigned)ntiles;
+        unsigned t;
+        unsigned n = roi_of(cur, t);
         unsigned p = 0;
         unsigned gl, gh;
         unsigned long long mask_cur = 0, mask_prev = 0;
@@ -702,7 +833,10 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             const Affine A = aff[pn];
             skip_cur = (dbg & 32) && A.batch >= batch_size;  // (a negative index still yields zeros)
             geometry(A, pt, pp, gl, gh, m);
-            if (lane == 0) shead[pp] = make_uint4(gl, gh, (unsigned)m, (unsigned)(m >> 32));
+            if (lane == 0) {
+                shead[pp] = make_uint4(gl, gh, (unsigned)m, (unsigned)(m >> 32));
+                sbatch[pp] = A.batch;
+            }
         };
         plan(n, t, 0, mask_cur);
         for (bool have_prev = false;; have_prev = true) {
@@ -721,8 +855,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             skip_prev = skip_cur;
             cur = next(cur);
             if (cur != kEnd) {
-                n = fdiv(cur, div_tiles);
-                t = cur - n * (unsigned)ntiles;
+                n = roi_of(cur, t);
                 p ^= 1u;
                 plan(n, t, p, mask_cur);  // while the gatherer blends the item before
             }
@@ -739,8 +872,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             wg_lds_barrier();  // 2
             break;
         }
-        const unsigned n = fdiv(cur, div_tiles);
-        const int batch = aff[n].batch;
+        const int batch = __builtin_amdgcn_readfirstlane(sbatch[p]);
         const uint4 hd = shead[p];
         g_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)hd.x);
         g_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)hd.y);

@@ -64,6 +64,62 @@ def test_forward_bit_exact(ext, oracle, name, path):
     assert n == 0 and d <= FWD_TOL, f"{n} elements differ, max |d| = {d}"
 
 
+@pytest.mark.parametrize("case", ["train_c64_b2", "c32_b3", "c40_b2_cl", "many_rois", "one_image_band", "more_images_than_buckets"])
+def test_forward_xcd_groups(ext, oracle, case):
+    """Round 5: C <= 64 (one or two channel chunks) and >= 64 ROIs take the XCD-GROUP form of the tiled forward -- the
+    ROIs are counting-sorted by (image, centre row) inside the prologue launch and each group of XCDs gathers one
+    quantile of them.  The order only ever decides WHO computes a crop: every case is bit-exact against the oracle,
+    including ROIs whose image index is invalid, centres at NaN and infinity (they sort to an end), more than
+    1024 ROIs (the sort's ranks beyond its registers go through memory), more images than the sort has buckets,
+    channels-last features consumed in place and channels-last crops."""
+    rng = np.random.default_rng(4242)
+    cl = False
+    if case == "train_c64_b2":
+        B, C, H, W, R, ph, pw = 2, 64, 120, 160, 300, 11, 83
+    elif case == "c32_b3":
+        B, C, H, W, R, ph, pw = 3, 32, 64, 96, 200, 8, 64
+    elif case == "c40_b2_cl":
+        B, C, H, W, R, ph, pw, cl = 2, 40, 50, 70, 130, 8, 40, True
+    elif case == "many_rois":
+        B, C, H, W, R, ph, pw = 2, 8, 40, 60, 1500, 4, 16
+    elif case == "one_image_band":
+        B, C, H, W, R, ph, pw = 4, 64, 48, 64, 128, 11, 32
+    else:
+        B, C, H, W, R, ph, pw = 1100, 4, 8, 8, 2300, 2, 8
+    f = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    h = rng.uniform(8, 40, R)
+    r = np.stack([rng.integers(0, B, R), rng.uniform(-10, 4 * W + 10, R), rng.uniform(-10, 4 * H + 10, R), h,
+                  h * rng.uniform(1, 8, R), rng.uniform(-90, 90, R)], 1).astype(np.float32)
+    if case == "one_image_band":          # every ROI in a thin band of image 2
+        r[:, 0], r[:, 2] = 2, rng.uniform(40, 60, R)
+    # invalid image indices (zeros here; the reference reads out of bounds, so the oracle gets a valid index and the
+    # rows are zeroed) and wild centres: they sort to the ends, the op treats them as the reference does
+    r[17, 2], r[19, 2], r[23, 2], r[29, 1] = np.nan, np.inf, -np.inf, np.nan
+    want = oracle.forward_c(f, r, ph, pw, 0.25, threads=8)
+    bad = [3, 7, 11]
+    r[3, 0], r[7, 0], r[11, 0] = -1, B, 1e9
+    want[bad] = 0
+    got = run_fwd(ext, f, r, ph, pw, 0.25, ext.PATH_TILED)
+    n, d = mismatch(got, want)
+    assert n == 0, f"{case}: {n} elements differ, max |d| = {d}"
+    if cl:
+        F = dev(f).contiguous(memory_format=torch.channels_last)
+        got_cl = ext.forward(F, dev(r), ph, pw, 0.25, path=ext.PATH_TILED)
+        assert eq(got_cl.cpu().numpy(), want)
+        out_cl = ext.forward(dev(f), dev(r), ph, pw, 0.25, path=ext.PATH_TILED, channels_last_out=True)
+        assert out_cl.is_contiguous(memory_format=torch.channels_last) and eq(out_cl.cpu().numpy(), want)
+    # the launches separately (the bench brackets them): the gather needs what THIS prologue wrote, the sort included
+    Fd, Rd = dev(f), dev(r)
+    out = torch.full((R, C, ph, pw), float("nan"), device="cuda")
+    nb = ext._lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, 0)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for stage in (ext.STAGE_PROLOGUE, ext.STAGE_GATHER):
+        assert ext._lib.rroi_align_forward_stages_hip(Fd.data_ptr(), 0, 0.25, B, R, H, W, C, ph, pw, Rd.data_ptr(), out.data_ptr(),
+                                                      ws.data_ptr(), nb, ext.PATH_TILED, stage, st) == 1
+    assert eq(out.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("path", ["direct", "tiled"])
 def test_forward_edge_and_degenerate_rois(ext, oracle, path):
     rng = np.random.default_rng(1)

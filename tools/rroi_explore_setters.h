@@ -71,3 +71,16 @@ int rroi_align_debug_set_waves_per_cu(int v)
     if (v >= 1 && v <= 64) g_tune.waves_per_cu = v;
     return old;
 }
+// XCD groups of the forward (round 5): 0 = one group (rounds 1-4), 1 = G = 8 / nchunks groups where the chunks divide the XCDs
+int rroi_align_debug_set_fwd_groups(int v)
+{
+    const int old = g_tune.fwd_groups;
+    g_tune.fwd_groups = v;
+    return old;
+}
+int rroi_align_debug_set_fwd_groups_min_rois(int v)
+{
+    const int old = g_tune.fwd_groups_min_rois;
+    g_tune.fwd_groups_min_rois = v;
+    return old;
+}
