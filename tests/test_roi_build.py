@@ -164,6 +164,35 @@ def test_ground_truth_module_and_degenerate_jitter(oracle):
 
 
 @pytest.mark.gpu
+def test_callers_follow_the_features_layout():
+    """Round 5: the two callers' modules hand the crops over in the FEATURES' layout by default
+    -- channels_last features give channels_last crops (same values, element for element), autograd brings the
+    gradient back channels_last and the feature gradient is written channels_last in place: no copy on either side.
+    NCHW features keep the reference's contract.  True / False force the layout."""
+    from rroi_align.batched import BatchedRRoiAlign, GroundTruthRRoiAlign
+    rng = np.random.default_rng(21)
+    f = rng.standard_normal((2, 64, 60, 80), dtype=np.float32)
+    q = torch.from_numpy(random_quads(24, seed=5, size=(320, 240))).cuda()
+    b = torch.from_numpy((np.arange(24) % 2).astype(np.float32)).cuda()
+    res = {}
+    for tag, fmt in (("nchw", torch.contiguous_format), ("cl", torch.channels_last)):
+        F = torch.from_numpy(f).cuda().contiguous(memory_format=fmt).requires_grad_(True)
+        crops, rois = GroundTruthRRoiAlign(11, 0.25)(F, q, b)
+        assert crops.is_contiguous(memory_format=fmt), tag
+        (crops * crops).sum().backward()
+        assert F.grad.is_contiguous(memory_format=fmt), tag
+        res[tag] = (crops.detach().clone(), F.grad.detach().clone())
+        c2, gw = BatchedRRoiAlign(11, 0.25, pooled_width=96)(F.detach(), q[:, :8], b)
+        assert c2.is_contiguous(memory_format=fmt), tag
+    assert torch.equal(res["nchw"][0], res["cl"][0])
+    scale = max(1.0, float(res["nchw"][1].abs().max()))
+    assert float((res["nchw"][1] - res["cl"][1]).abs().max()) <= 1e-4 * scale
+    Fc = torch.from_numpy(f).cuda().contiguous(memory_format=torch.channels_last)
+    forced, _ = GroundTruthRRoiAlign(11, 0.25, channels_last_out=False)(Fc, q, b)
+    assert forced.is_contiguous() and torch.equal(forced, res["nchw"][0])
+
+
+@pytest.mark.gpu
 def test_batched_launch_equals_per_box_launches(oracle):
     """One launch for all boxes of an image == the reference's loop of R = 1 launches
     (tools/ocr_utils.py:147-177): identical on each box's own width target_gw[i].  Beyond it the
