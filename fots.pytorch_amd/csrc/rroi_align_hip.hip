@@ -92,6 +92,10 @@ struct Tuning {
     int shift_wgs_per_cu = 0;     // > 0 overrides the SHIFT kernels' workgroups per CU
     int fwd_dbg = 0;              // ablations: 1 = skip output stores, 2 = all taps out of range, 256 = free first item
     int prologue_blocks_per_cu = 3;
+    int fwd_fused = 1;            // AUTO may take the one-launch gather from the NCHW map for few ROIs (round 5)
+    double fwd_fused_min_elems = 1.5e6;   // ... from this many output elements up (below: the direct kernel) ...
+    int fwd_fused_min_channels = 128;     // ... and this many channels
+    double fwd_tiled_min_elems = 3.0e6;   // ... and the two-launch path from this many up
     int fwd_groups = 1;           // XCD groups for nchunks in {1, 2} (round 5; XcdGroups in rroi_forward_kernels.h); 0: off
     int fwd_groups_min_rois = 64; // ... from this many ROIs up
     int bwd_buckets = 1;          // one-pass pixel lists (round 3); 0: count / scan / fill as in rounds 1-2
@@ -332,7 +336,22 @@ bool pick_tiled_fwd(int batch_size, int channels, int height, int width, int num
 {
     const double out_elems = (double)num_rois * channels * NB;
     const double map_elems = (double)batch_size * channels * height * width;
-    return out_elems >= 3.0e6 && out_elems >= map_elems / 4;
+    return out_elems >= g_tune.fwd_tiled_min_elems && out_elems >= map_elems / 4;
+}
+// Below the two-launch path's crossover: the one-launch gather from the NCHW map (RROI_PATH_FUSED) or the thread-per-bin
+// direct kernel?  Measured (tools/fused_probe.py, profiles/r05_fused_probe.txt; us per call, direct / fused / tiled):
+//   C = 64, two 120 x 160 maps, 11 x 96:  R = 8  5.0 / 6.6 / 10.8,  16  7.4 / 7.9 / 11.0,  32  10.5 / 11.7 / 12.1,  64  16.6 / 17.9 / 13.0
+//   C = 128, 160 x 160, 8 x 64:           R = 32  12.2 / 8.2 / 11.4
+//   C = 256, 160 x 160, 8 x 64:           R = 8  7.0 / 7.4 / 13.9,  16  14.7 / 9.7 / 14.3,  32  35.8 / 16.0 / 15.4
+// Both one-launch forms pay per output element (the direct kernel VALU and address work per bin and channel, the fused
+// one four dword loads per tap) and meet at ~1.5 M elements; the fused form's per-ROI geometry is shared by 32 channels
+// instead of 4-16, so it wins from there up to the two-launch path's crossover WHEN THERE ARE CHANNELS TO SHARE IT: C >= 128.
+// At the reference's own C = 64 the direct kernel stays ahead up to the two-launch path (profiles/r05_small_r_forward.md).
+bool pick_fused_fwd(int batch_size, int channels, int height, int width, int num_rois, int NB)
+{
+    (void)batch_size; (void)height; (void)width;
+    const double out_elems = (double)num_rois * channels * NB;
+    return g_tune.fwd_fused && channels >= g_tune.fwd_fused_min_channels && out_elems >= g_tune.fwd_fused_min_elems;
 }
 bool pick_tiled_bwd(int batch_size, int channels, int height, int width, int num_rois, int NB)
 {
@@ -615,7 +634,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     if (!shape_ok(batch_size, num_rois, height, width, channels, pooled_height, pooled_width))
         return 0;
     if (feature_layout != RROI_LAYOUT_NCHW && feature_layout != RROI_LAYOUT_NHWC) return 0;
-    if (path != RROI_PATH_AUTO && path != RROI_PATH_DIRECT && path != RROI_PATH_TILED) return 0;
+    if (path != RROI_PATH_AUTO && path != RROI_PATH_DIRECT && path != RROI_PATH_TILED && path != RROI_PATH_FUSED) return 0;
     if (num_rois == 0) return 1;
     if (!features || !rois || !top_data) return 0;
     const int NB = pooled_height * pooled_width;
@@ -628,6 +647,34 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
                 pick_tiled_fwd(batch_size, channels, height, width, num_rois, NB);
     else
         tiled = path == RROI_PATH_TILED;
+    // the one-launch form for few ROIs (the gather reading the NCHW map itself): NCHW in, NCHW out, not for the launcher
+    const bool fused = !launcher_rest && !out_nhwc && feature_layout == RROI_LAYOUT_NCHW &&
+                       (path == RROI_PATH_FUSED ||
+                        (path == RROI_PATH_AUTO && !tiled && pick_fused_fwd(batch_size, channels, height, width, num_rois, NB)));
+    if (path == RROI_PATH_FUSED && !fused) return 0;
+    if (fused) {
+        if (!(stages & RROI_STAGE_GATHER)) return 1;  // one launch, run under the gather stage
+        const int nchunks = ceil_div(channels, kChunk);
+        const ForwardPlan plan = plan_forward_gather(num_rois, channels, NB, nchunks, false, false);
+        if ((long)num_rois * plan.ntiles >= (1L << 31)) return 0;
+        const unsigned HWu = (unsigned)height * (unsigned)width;
+        SliceLayout lay;
+        lay.px_bytes = 4u;                       // a "pixel" of a channel plane
+        lay.row_bytes = (unsigned)width * 4u;
+        lay.slice_bytes = HWu * 4u;              // ONE plane: the kernel's descriptor covers the chunk's planes < C
+        lay.chunk_stride = kChunk * HWu;         // floats (shape_ok: C * H * W * 4 < 2^30)
+        lay.img_stride = (unsigned)channels * HWu;
+        const FastDiv dt = make_fastdiv((unsigned)plan.ntiles), dp = make_fastdiv((unsigned)pooled_width);
+        const RoiSource rsrc = {rois, pooled_height, spatial_scale, trig};
+#define RROI_FUSED(...)                                                                                                   \
+    hipLaunchKernelGGL((rroi_fwd_split_kernel<__VA_ARGS__>), dim3(plan.grid), dim3(2 * kWave), 0, stream, features,          \
+                       (const Affine*)nullptr, top_data, num_rois, channels, height, width, pooled_width, NB, batch_size,    \
+                       nchunks, plan.ntiles, lay, dt, dp, plan.dbg, XcdGroups{1, nullptr}, rsrc)
+        if (plan.kernel == FwdKernel::kShift) RROI_FUSED(true, 0, 4, 3, false, 1, true);
+        else RROI_FUSED(true, 0, 4, 3, false, 0, true);
+#undef RROI_FUSED
+        return launch_status();
+    }
     if (!tiled && feature_layout != RROI_LAYOUT_NCHW) return 0;  // direct path reads NCHW only
 
     if (!tiled) {

@@ -417,11 +417,25 @@ constexpr int kShiftAux = RROI_SHIFT_AUX;
 __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 
-template <bool VEC_STORE, int EARLY, int OCC, int HID, bool ONHWC, int SHIFT>
+// NCHW_SRC (round 5, RROI_PATH_FUSED): the ONE-LAUNCH form for few ROIs -- the reference's own call shapes: at most 32 ROIs
+// per training step (src/ocr_process.py:253-255), 1 ... 24 per image in inference.  No prologue launch at all: `map` is the
+// caller's NCHW tensor, a "slice" is the 32 channel PLANES of chunk k, a lane's four channels of a pixel are four dword
+// loads a plane apart instead of one 16-byte load (four times the load instructions per item -- the price of not relaying
+// out a whole map for a handful of crops; it is the address rate that bounds this form, so it serves few ROIs only), and the
+// storer wave evaluates the affine of its item's ROI itself (`roi_src`).  Everything else -- records, class-sorted groups,
+// blend, tile, stores -- is the two-launch form's, bit for bit.
+struct RoiSource {   // NCHW_SRC: where the storer takes its affines from
+    const float* rois;
+    int pooled_height;
+    float spatial_scale;
+    int trig;
+};
+template <bool VEC_STORE, int EARLY, int OCC, int HID, bool ONHWC, int SHIFT, bool NCHW_SRC = false>
 __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
-    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg, XcdGroups xg)
+    int nchunks, int ntiles, SliceLayout lay, FastDiv div_tiles, FastDiv div_pw, int dbg, XcdGroups xg,
+    RoiSource roi_src = RoiSource{nullptr, 0, 0.0f, 0})
 {
     // A tile's bins are processed in CLASS-SORTED groups of 8, because the texture addresser
     // charges 16 cycles for every dwordx4 wave instruction whatever the number of lanes that
@@ -495,7 +509,10 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // measured 43 vs 16 TCP accesses per load instruction.)
     const unsigned q = lane & (kQuads - 1), b = lane >> 3;
     // a channel quad wholly beyond C never loads (its rows are not stored either)
-    const unsigned q_bytes = ((dbg & 2) || k * kChunk + q * 4 >= (unsigned)C) ? kQuadOOB : q * 16u;
+    // NCHW_SRC: lay.slice_bytes is ONE channel plane (H * W * 4 bytes); the quad's first channel is 4 q planes into the chunk
+    const unsigned plane_bytes = lay.slice_bytes;
+    const unsigned q_bytes = ((dbg & 2) || k * kChunk + q * 4 >= (unsigned)C) ? kQuadOOB
+                             : (NCHW_SRC ? q * 4u * plane_bytes : q * 16u);
     // LDS tile: row r = channel, 68-dword pitch; the column of rows 8m..8m+7 is XORed with
     // 4*m so that the 32 lanes of a store group (8 quads x 4 bins) spread over the banks
     // while rows stay 16-byte aligned for the ds_read_b128 of phase C.
@@ -576,17 +593,28 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         ra[s] = Gbuf[p * kRecs + grp * kBinsPerIter + b];
         hpos[s] = HPbuf[p * kRecs + grp * kBinsPerIter + b];
     };
+    // one tap of the lane's four channels: a 16-byte load of the chunk-major / channels-last pixel, or (NCHW_SRC) four
+    // dwords a plane apart -- a channel beyond C is beyond the descriptor's range (chans_here planes) and reads 0.0
+    auto tap4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off) -> v4f {
+        if (!NCHW_SRC) return buf_load(rs, off);
+        v4f v;
+        v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+        v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + plane_bytes, 0, 0));
+        v.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + 2u * plane_bytes, 0, 0));
+        v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + 3u * plane_bytes, 0, 0));
+        return v;
+    };
     auto issue_lo = [&](__amdgpu_buffer_rsrc_t rs, int s) {
-        // offsets are < 2^30 or kOOB = 2^31, q_bytes is < 128 or kQuadOOB = 2^30: every sum with an
-        // out-of-range term lies in [2^30, 2^32) -- beyond any slice (shape_ok), and it cannot wrap
-        lt[s] = buf_load(rs, ra[s].x + q_bytes);
-        rt[s] = buf_load(rs, ra[s].y + q_bytes);  // the bin's one other distinct tap, if any
+        // offsets are < 2^30 or kOOB = 2^31, q_bytes is < 128 (NCHW_SRC: < 2^30 less four planes) or kQuadOOB = 2^30: every
+        // sum with an out-of-range term lies in [2^30, 2^32) -- beyond any slice (shape_ok), and it cannot wrap
+        lt[s] = tap4(rs, ra[s].x + q_bytes);
+        rt[s] = tap4(rs, ra[s].y + q_bytes);  // the bin's one other distinct tap, if any
     };
     auto issue_hi = [&](__amdgpu_buffer_rsrc_t rs, int s) {
-        lt[s] = buf_load(rs, ra[s].x + q_bytes);
-        rt[s] = buf_load(rs, ra[s].y + q_bytes);
-        lb[s] = buf_load(rs, ra[s].z + q_bytes);
-        rbv[s] = buf_load(rs, ra[s].w + q_bytes);
+        lt[s] = tap4(rs, ra[s].x + q_bytes);
+        rt[s] = tap4(rs, ra[s].y + q_bytes);
+        lb[s] = tap4(rs, ra[s].z + q_bytes);
+        rbv[s] = tap4(rs, ra[s].w + q_bytes);
     };
     float* const t_row = T + (q * 4) * kTStride;
     float* const t_pad = T + kChunk * kTStride + (lane & 31u);
@@ -830,7 +858,8 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         // written by the prologue launch -- they are not zero-filled here
         bool skip_cur = false, skip_prev = false;
         auto plan = [&](unsigned pn, unsigned pt, unsigned pp, unsigned long long& m) {
-            const Affine A = aff[pn];
+            const Affine A = NCHW_SRC ? make_affine(roi_src.rois + (size_t)pn * 6, roi_src.pooled_height, roi_src.spatial_scale, roi_src.trig)
+                                      : aff[pn];
             skip_cur = (dbg & 32) && A.batch >= batch_size;  // (a negative index still yields zeros)
             geometry(A, pt, pp, gl, gh, m);
             if (lane == 0) {
@@ -878,7 +907,8 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         g_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)hd.y);
         const bool batch_ok = batch >= 0 && batch < batch_size;
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(
-            map + (size_t)(batch_ok ? batch : 0) * lay.img_stride + (size_t)k * lay.chunk_stride, lay.slice_bytes);
+            map + (size_t)(batch_ok ? batch : 0) * lay.img_stride + (size_t)k * lay.chunk_stride,
+            NCHW_SRC ? chans_here * plane_bytes : lay.slice_bytes);
         // the first kEarly LO groups go out while the storer takes the previous tile out of T,
         // unconditionally (a record beyond the item's LO groups is a HI record, padding or stale: its
         // offsets are in range or kOOB, the data is never used) -- straight-line code keeps the s_waitcnt

@@ -23,12 +23,13 @@ LIB_PATH = os.path.join(_HERE, "librroi_align_hip.so")
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 PATH_AUTO, PATH_DIRECT, PATH_TILED, PATH_TILED_ATOMIC, PATH_TILED_LISTS, PATH_TILED_INKERNEL = 0, 1, 2, 3, 4, 5
 PATH_TILED_BUCKETS = 6  # backward only: the gather over pixel lists built in one pass (buckets + overflow chains)
+PATH_FUSED = 7  # forward only: one launch for few ROIs, the tiled gather reading the NCHW map itself (no workspace)
 # the gather formulations of the backward (they also read / write channels-last tensors in place), and every path
 GATHER_PATHS = (PATH_TILED, PATH_TILED_LISTS, PATH_TILED_BUCKETS, PATH_TILED_INKERNEL)
 BACKWARD_PATHS = (PATH_AUTO, PATH_DIRECT, PATH_TILED_ATOMIC) + GATHER_PATHS
 STAGE_PROLOGUE, STAGE_GATHER, STAGE_ALL = 1, 2, 3
 # every value `path` may take in forward() (the parity tests run them all)
-FORWARD_PATHS = (PATH_AUTO, PATH_DIRECT, PATH_TILED)
+FORWARD_PATHS = (PATH_AUTO, PATH_DIRECT, PATH_TILED, PATH_FUSED)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -202,19 +203,19 @@ def forward(features: torch.Tensor, rois: torch.Tensor, pooled_height: int, pool
         raise ValueError("pooled_height and pooled_width must be positive")
     if features.is_contiguous():
         layout = LAYOUT_NCHW
-    elif features.is_contiguous(memory_format=torch.channels_last) and C % 4 == 0 and path != PATH_DIRECT:
+    elif features.is_contiguous(memory_format=torch.channels_last) and C % 4 == 0 and path not in (PATH_DIRECT, PATH_FUSED):
         layout = LAYOUT_NHWC  # consumed in place: a pixel's channels are already contiguous
     else:
         features, layout = features.contiguous(), LAYOUT_NCHW
     rois = rois.contiguous()
-    if channels_last_out and (C % 4 != 0 or path == PATH_DIRECT):
+    if channels_last_out and (C % 4 != 0 or path in (PATH_DIRECT, PATH_FUSED)):
         raise ValueError("channels_last_out needs C % 4 == 0 and the tiled path")
     with torch.cuda.device_of(features):
         out = torch.empty((R, C, ph, pw), dtype=torch.float32, device=features.device,
                           memory_format=torch.channels_last if channels_last_out else torch.contiguous_format)
         if R == 0 or out.numel() == 0:
             return out
-        nbytes = 0 if path == PATH_DIRECT else _lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, layout)
+        nbytes = 0 if path in (PATH_DIRECT, PATH_FUSED) else _lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, layout)
         ws = _workspace(features.device, nbytes)
         st = _lib.rroi_align_forward_layout_hip(features.data_ptr(), layout,
                                                 LAYOUT_NHWC if channels_last_out else LAYOUT_NCHW,

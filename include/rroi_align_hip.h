@@ -92,6 +92,11 @@ int rroi_align_release_launcher_scratch(void);
                                     fixed-capacity buckets per pixel plus overflow chains: no count pass, no
                                     scan.  What AUTO / TILED run (the bucket grows with the density, 16 ..
                                     4096 entries, under a memory cap); any density is accepted when named    */
+#define RROI_PATH_FUSED 7   /* forward only (round 5): ONE launch for few ROIs -- the tiled gather reading the NCHW map
+                                    itself (four dword loads per tap instead of one 16-byte load from a relaid-out copy)
+                                    and evaluating the affines itself: no prologue launch, no workspace (NULL / 0 is
+                                    accepted).  NCHW features and crops only.  What AUTO runs between the direct kernel
+                                    (a handful of ROIs) and the two-launch path                                     */
 #define RROI_PATH_TILED_INKERNEL 5 /* backward only: the gather that finds each map tile's bins
                                     inside the kernel, no lists in HBM.  Round 2's choice for C <= 64;
                                     since round 3 AUTO / TILED reach it only where the buckets are not

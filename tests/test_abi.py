@@ -147,8 +147,8 @@ def test_python_constants_are_the_headers():
     for name, value in defs.items():
         assert getattr(ext, name) == value, name
     # path values live in the low byte, flags above it
-    assert set(ext.BACKWARD_PATHS) == {v for k, v in defs.items() if k.startswith("PATH_") and v < 0x100}
-    assert set(ext.FORWARD_PATHS) <= set(ext.BACKWARD_PATHS)
+    assert set(ext.BACKWARD_PATHS) | {ext.PATH_FUSED} == {v for k, v in defs.items() if k.startswith("PATH_") and v < 0x100}
+    assert set(ext.FORWARD_PATHS) <= set(ext.BACKWARD_PATHS) | {ext.PATH_FUSED}   # (FUSED: forward only)
 
 
 @pytest.mark.gpu

@@ -53,12 +53,12 @@ SHAPES = {
 }
 
 
-@pytest.mark.parametrize("path", ["direct", "tiled", "auto"])
+@pytest.mark.parametrize("path", ["direct", "tiled", "fused", "auto"])
 @pytest.mark.parametrize("name", list(SHAPES))
 def test_forward_bit_exact(ext, oracle, name, path):
     f, r, ph, pw, s = SHAPES[name]()
     want = oracle.forward_c(f, r, ph, pw, s, threads=8)
-    got = run_fwd(ext, f, r, ph, pw, s, {"direct": ext.PATH_DIRECT, "tiled": ext.PATH_TILED,
+    got = run_fwd(ext, f, r, ph, pw, s, {"direct": ext.PATH_DIRECT, "tiled": ext.PATH_TILED, "fused": ext.PATH_FUSED,
                                          "auto": ext.PATH_AUTO}[path])
     n, d = mismatch(got, want)
     assert n == 0 and d <= FWD_TOL, f"{n} elements differ, max |d| = {d}"
@@ -120,11 +120,11 @@ def test_forward_xcd_groups(ext, oracle, case):
     assert eq(out.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("path", ["direct", "tiled"])
+@pytest.mark.parametrize("path", ["direct", "tiled", "fused"])
 def test_forward_edge_and_degenerate_rois(ext, oracle, path):
     rng = np.random.default_rng(1)
     f = rng.standard_normal((1, 36, 160, 160), dtype=np.float32)
-    p = ext.PATH_DIRECT if path == "direct" else ext.PATH_TILED
+    p = {"direct": ext.PATH_DIRECT, "tiled": ext.PATH_TILED, "fused": ext.PATH_FUSED}[path]
     for rois in (Wk.edge_rois(), Wk.degenerate_rois()):
         want = oracle.forward_c(f, rois, 8, 64, 0.25)
         got = run_fwd(ext, f, rois, 8, 64, 0.25, p)
@@ -138,7 +138,7 @@ def test_forward_nonfinite_features(ext, oracle):
     f[0, :, 40:44, 50:54] = np.inf
     f[0, :, 90, 100] = np.nan
     want = oracle.forward_c(f, r, 8, 64, 0.25)
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_FUSED):
         assert mismatch(run_fwd(ext, f, r, 8, 64, 0.25, p), want)[0] == 0
 
 
@@ -158,7 +158,7 @@ def test_forward_nonfinite_scattered(ext, oracle):
     f[0, ::2, (sel >= 0.024) & (sel < 0.030)] = -3.0e38
     want = oracle.forward_c(f, r, 8, 64, 0.25)
     assert np.isnan(want).any() and np.isinf(want).any()
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_FUSED):
         n, d = mismatch(run_fwd(ext, f, r, 8, 64, 0.25, p), want)
         assert n == 0, f"path {p}: {n} elements differ"
 
@@ -168,7 +168,7 @@ def test_golden_fixtures(ext, name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     ph, pw = (int(v) for v in z["pooled"])
     s = float(z["scale"])
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_FUSED):
         assert eq(run_fwd(ext, z["features"], z["rois"], ph, pw, s, p), z["out"])
     H, W = z["features"].shape[2:]
     geom = ext.bin_centres(dev(z["rois"]), ph, pw, s, H, W).cpu().numpy()
@@ -252,7 +252,7 @@ def test_more_than_256_channels(ext, oracle):
     and the gather backward needs a second channel pass (64 lanes cover 8 chunks)."""
     f, r = Wk.bench_inputs(R=20, C=300, H=40, W=56, img=224, seed=41, batch=2)
     want = oracle.forward_c(f, r, 8, 32, 0.25, threads=8)
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_FUSED):
         assert mismatch(run_fwd(ext, f, r, 8, 32, 0.25, p), want)[0] == 0
     gout = np.random.default_rng(41).standard_normal(want.shape).astype(np.float32)
     gwant = oracle.backward_c(gout, r, f.shape, 0.25)
@@ -695,7 +695,7 @@ def test_invalid_batch_index_yields_zeros(ext):
     f, r = Wk.bench_inputs(R=4, C=8, seed=18)
     r[1, 0] = 5
     r[2, 0] = -3
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_FUSED):
         out = run_fwd(ext, f, r, 8, 64, 0.25, p)
         assert not out[1].any() and not out[2].any() and out[0].any() and out[3].any()
 
@@ -730,7 +730,7 @@ def test_random_shape_sweep(ext, oracle):
         r[:, 3] = rng.uniform(2, 40, R) / (s * 4)
         r[:, 4] = r[:, 3] * rng.uniform(0.3, 12, R)
         want = oracle.forward_c(f, r, ph, pw, s, threads=8)
-        for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+        for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_FUSED):
             got = run_fwd(ext, f, r, ph, pw, s, p)
             n, d = mismatch(got, want)
             assert n == 0, f"trial {trial} C={C} {H}x{W} B={B} {ph}x{pw} s={s} R={R} path={p}: {n} differ (max {d})"

@@ -84,3 +84,12 @@ int rroi_align_debug_set_fwd_groups_min_rois(int v)
     g_tune.fwd_groups_min_rois = v;
     return old;
 }
+// AUTO's forward crossovers: one-launch fused form on / off, its lower bound and the two-launch path's, in output elements (<= 0: leave)
+int rroi_align_debug_set_fwd_fused(int on, double fused_min, double tiled_min)
+{
+    const int old = g_tune.fwd_fused;
+    g_tune.fwd_fused = on;
+    if (fused_min > 0) g_tune.fwd_fused_min_elems = fused_min;
+    if (tiled_min > 0) g_tune.fwd_tiled_min_elems = tiled_min;
+    return old;
+}
