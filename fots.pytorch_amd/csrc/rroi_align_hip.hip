@@ -99,6 +99,8 @@ struct Tuning {
     int fwd_groups = 1;           // XCD groups for nchunks in {1, 2} (round 5; XcdGroups in rroi_forward_kernels.h); 0: off
     int fwd_groups_min_rois = 64; // ... from this many ROIs up
     int bwd_buckets = 1;          // one-pass pixel lists (round 3); 0: count / scan / fill as in rounds 1-2
+    int bwd_pair_aggregate = 1;       // bucket slots reserved per wave through LDS (round 5); 0: one atomic per pair
+    int bwd_pair_blocks_per_cu = 0;   // 0: 256 / C, clamped to 2 .. 4 (see backward_impl)
     int bwd_tile_run = 2;         // the in-place NCHW gather: 2^v neighbouring key tiles per XCD turn
     int bwd_skip_dead = 1;        // the relayout of top_diff leaves out the bins that enter no list (round 4)
     int bwd_nchw_direct = 16;     // the list gather stores an NCHW bottom_diff itself (round 4): always for C <= 128, up to this
@@ -966,7 +968,24 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
         const PatchMap dnb = make_patch_map(pooled_height, pooled_width);
         if ((long)num_rois * dnb.lanes_per_roi >= (1L << 32)) return 0;
         int pblocks = ceil_div((long)num_rois * dnb.lanes_per_roi, 256);
-        if (pblocks > num_cus()) pblocks = num_cus();
+        {
+            // pair blocks per CU.  A pair wave walks a chain of returning atomics (~2.5 us per patch of 64 bins under
+            // load), so its launch time is patches per wave x that; the relayout it shares the launch with takes
+            // bytes / bandwidth.  One block per CU hides the pairs behind the relayout of 256 channels (round 2); with
+            // FEWER channels the same bins bring a quarter of the bytes and the pair pass set the launch (R = 512, C = 64,
+            // 11 x 96: 58 us where the relayout alone takes 30): blocks per CU ~ 256 / C.
+            // (tools/pair_blocks_ab.py, profiles/r05_pair_blocks_ab2.txt: with the wave-aggregated reservations, us per call at 1 / 2
+            // / 4 / 8 blocks per CU -- C = 64, R = 512, 11 x 96: 90.6 / 73.0 / 67.0 / 68.8 (round 4: 84.3); C = 128: 66.5 / 58.9 /
+            // 59.7 / 59.7; configs[2]: 104.4 / 103.3 / 103.6 / 103.5)
+            int per_cu = g_tune.bwd_pair_blocks_per_cu;
+            if (per_cu <= 0) per_cu = std::min(4, std::max(2, 256 / std::max(channels, 1)));
+            const long cap = (long)num_cus() * per_cu;
+            if (pblocks > cap) pblocks = (int)cap;
+        }
+        // the bucket slots reserved per WAVE through a table in LDS (pairs_reserve_wave) -- where a wave has several
+        // patches to walk; with one patch per wave the table's set-up is pure latency (R = 32, C = 64: +0.8 us)
+        const bool aggregate = g_tune.bwd_pair_aggregate &&
+                               (long)num_rois * (dnb.lanes_per_roi / 64) > 8L * num_cus();
         // count || first half of the relayout;  scan;  fill || second half.  The relayout is the
         // forward's, with R "images" of PH x PW "pixels" and the masked bins skipped:
         // top_diff (R, C, NB) -> (R, NB, nchunks * 32)
@@ -984,7 +1003,7 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
                        dim3(256), 0, stream, ws.aff, num_rois, height, width, pooled_width, NB,          \
                        batch_size, lines_per_roi, dnb, dpw, KL, ws.cnt, ws.off, ws.bsum, ws.pairs,       \
                        pblocks, top_diff, ws.tdT, channels, nchunks, tt, (int)(BLOCKS), (int)(T0), (int)(T1),            \
-                       ws.scan_blocks, raw_bsum, BL, g_tune.bwd_skip_dead)
+                       ws.scan_blocks, raw_bsum, BL, (g_tune.bwd_skip_dead ? 1 : 0) | (aggregate ? 2 : 0))
         if (buckets) {
             // ONE launch: every pair into its pixel's bucket (or overflow chain) || the whole relayout
             const long blocks = relayout_grid(tiles);

@@ -115,6 +115,68 @@ struct BucketLists {
     uint4* ov;                    // {bin line, weight bits, next, -}; room for every pair of the problem
 };
 
+// MODE 2 with the slot reservations AGGREGATED PER WAVE (round 5).  Device-scope atomics are bound by the number of
+// 128-byte line REQUESTS, and a patch of 64 bins issued four atomic instructions (one per tap) that each touched the same
+// half dozen 8 x 4-pixel counter tiles: with the reference's C = 64 -- the same bins, a quarter of the relayout's bytes --
+// the pair pass set the launch (R = 512, 11 x 96: 58 us where the relayout alone takes 30).  Now a wave first counts its
+// <= 256 pairs in a table in LDS -- up to kAggTiles counter tiles x 32 pixels, found with a small open-addressing probe;
+// LDS atomics hand out the rank inside the wave --, then reserves the slots with ONE global atomic instruction per tile
+// (lane = pixel of the tile: one line request carries all its counts), and every pair's slot is the tile's returned base
+// plus its rank.  A pair whose tile finds no room in the table takes its slot alone, as before.  All 64 lanes of the wave
+// call this together (lanes without a bin pass npairs = 0).
+constexpr unsigned kAggTiles = 16;
+constexpr unsigned kAggWords = kAggTiles + 2u * kAggTiles * 32u;   // ids | counts | bases: 1040 words per wave
+constexpr unsigned kAggEmpty = 0xffffffffu;
+__device__ __forceinline__ void pairs_reserve_wave(unsigned* __restrict__ tab, const unsigned (&keys)[4], unsigned npairs,
+                                                   int* __restrict__ cnt, unsigned (&slots)[4])
+{
+    unsigned* const ids = tab;
+    unsigned* const counts = tab + kAggTiles;
+    unsigned* const bases = counts + kAggTiles * 32u;
+    const unsigned lane = threadIdx.x & 63u;
+    // clear: 16 ids + 512 counts (the bases are written before they are read)
+    if (lane < kAggTiles) ids[lane] = kAggEmpty;
+#pragma unroll
+    for (unsigned e = 0; e < kAggTiles * 32u / kWave; ++e) counts[e * kWave + lane] = 0u;
+    lds_wave_sync();
+    // slots[p] doubles as (table entry | rank << 16) until the bases are known: registers are what keeps this kernel at
+    // seven waves per SIMD
+    constexpr unsigned kNoEntry = 0xffffu;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        slots[p] = kNoEntry;
+        if ((unsigned)p < npairs) {
+            const unsigned tile = keys[p] >> 5, in = keys[p] & 31u;
+            unsigned h = (tile ^ (tile >> 4)) & (kAggTiles - 1u);
+            for (unsigned probe = 0; probe < kAggTiles; ++probe, h = (h + 1u) & (kAggTiles - 1u)) {
+                const unsigned old = atomicCAS(ids + h, kAggEmpty, tile);
+                if (old == kAggEmpty || old == tile) {
+                    slots[p] = h * 32u + in;
+                    break;
+                }
+            }
+            if (slots[p] != kNoEntry) slots[p] |= atomicAdd(counts + slots[p], 1u) << 16;   // (a wave has at most 256 pairs)
+        }
+    }
+    lds_wave_sync();
+    // one global atomic instruction per pair of table rows: lane = (row of two, pixel); empty rows cost nothing
+#pragma unroll
+    for (unsigned r2 = 0; r2 < kAggTiles / 2u; ++r2) {
+        const unsigned row = r2 * 2u + (lane >> 5), in = lane & 31u;
+        const unsigned tile = ids[row];
+        const unsigned c = tile != kAggEmpty ? counts[row * 32u + in] : 0u;
+        if (c) bases[row * 32u + in] = (unsigned)atomicAdd(cnt + (tile << 5) + in, (int)c);
+    }
+    lds_wave_sync();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if ((unsigned)p >= npairs) continue;
+        slots[p] = (slots[p] & 0xffffu) != kNoEntry ? bases[slots[p] & 0xffffu] + (slots[p] >> 16)
+                                                    : (unsigned)atomicAdd(cnt + keys[p], 1);
+    }
+    lds_wave_sync();   // (the table is cleared again by this wave's next patch)
+}
+
 // MODE 0: cnt[key] += 1 per pair (count pass).  MODE 1: cnt counts back down, handing out the slots of
 // the key's segment (fill pass, after the scan).  MODE 2 (round 3): ONE pass -- cnt[key]++ hands out the
 // slots of a fixed-capacity bucket per pixel (a few times the average list), the rare pair beyond it is
@@ -125,31 +187,57 @@ __device__ __forceinline__ void pairs_body(unsigned idx, const Affine* __restric
                                            unsigned lines_per_roi, const PatchMap& pm,
                                            const KeyLayout& L, int* __restrict__ cnt,
                                            const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
-                                           uint2* __restrict__ pairs, const BucketLists& bl)
+                                           uint2* __restrict__ pairs, const BucketLists& bl, unsigned* __restrict__ agg = nullptr)
 {
     constexpr bool FILL = MODE == 1;
+    // (the lanes of a wave share the ROI and the patch: idx is a multiple of 64 plus the lane, the total a multiple of 64)
     const unsigned n = fdiv(idx, pm.div_roi);
-    if (n >= (unsigned)num_rois) return;
     const unsigned rem = idx - n * pm.lanes_per_roi;
     const unsigned patch = rem >> 6, l = rem & 63u;
     const unsigned py = fdiv(patch, pm.div_npx), px = patch - py * pm.npx;
     const unsigned ph = py * (64u >> pm.pc_shift) + (l >> pm.pc_shift);
     const unsigned pw = (px << pm.pc_shift) + (l & ((1u << pm.pc_shift) - 1u));
-    if (ph >= (unsigned)pooled_height || pw >= (unsigned)pooled_width) return;
+    const bool has_bin = n < (unsigned)num_rois && ph < (unsigned)pooled_height && pw < (unsigned)pooled_width;
     const unsigned j = ph * (unsigned)pooled_width + pw;
-    const Affine A = aff[n];
-    bin_pairs(A, ph, pw, height, width, batch_size, L, [&](unsigned key, float w) {
-        if (MODE == 2) {
-            const unsigned slot = (unsigned)atomicAdd(cnt + key, 1);
-            const uint2 rec = make_uint2(n * lines_per_roi + j, as_u(w));
-            if (slot < (1u << bl.kshift)) {
-                pairs[((size_t)key << bl.kshift) + slot] = rec;
+    if (MODE == 2) {
+        // every lane of the wave gets here: the slots are reserved by the wave as a whole (pairs_reserve_wave)
+        unsigned keys[4] = {0u, 0u, 0u, 0u}, np = 0u, slots[4] = {0u, 0u, 0u, 0u};
+        float wts[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has_bin) {
+            const Affine A = aff[n];
+            bin_pairs(A, ph, pw, height, width, batch_size, L, [&](unsigned key, float w) {   // at most four calls
+                if (np == 0) { keys[0] = key; wts[0] = w; }
+                else if (np == 1) { keys[1] = key; wts[1] = w; }
+                else if (np == 2) { keys[2] = key; wts[2] = w; }
+                else { keys[3] = key; wts[3] = w; }
+                ++np;
+            });
+        }
+        if (agg) {
+            pairs_reserve_wave(agg, keys, np, cnt, slots);
+        } else {   // few patches per wave: one returning atomic per pair, no table to set up
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if ((unsigned)p < np) slots[p] = (unsigned)atomicAdd(cnt + keys[p], 1);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if ((unsigned)p >= np) continue;
+            const uint2 rec = make_uint2(n * lines_per_roi + j, as_u(wts[p]));
+            if (slots[p] < (1u << bl.kshift)) {
+                pairs[((size_t)keys[p] << bl.kshift) + slots[p]] = rec;
             } else {
                 const unsigned e = atomicAdd(bl.ovcnt, 1u);
-                const int prev = atomicExch(bl.head + key, (int)e);
+                const int prev = atomicExch(bl.head + keys[p], (int)e);
                 bl.ov[e] = make_uint4(rec.x, rec.y, (unsigned)prev, 0u);
             }
-        } else if (!FILL) {
+        }
+        return;
+    }
+    if (!has_bin) return;
+    const Affine A = aff[n];
+    bin_pairs(A, ph, pw, height, width, batch_size, L, [&](unsigned key, float w) {
+        if (!FILL) {
             atomicAdd(cnt + key, 1);
         } else {
             const int slot = atomicAdd(cnt + key, -1) - 1;
@@ -164,28 +252,30 @@ __device__ __forceinline__ void pairs_body(unsigned idx, const Affine* __restric
 // [tile_begin, tile_end) of top_diff -- bound by HBM.  They share the chip instead of running
 // one after the other; the host gives each of the two launches half of the tiles.
 template <int MODE, int SAUX>
-__global__ __launch_bounds__(256) void rroi_bwd_pairs_relayout_kernel(
+__global__ __launch_bounds__(256, 7) void rroi_bwd_pairs_relayout_kernel(   // (seven workgroups per CU: <= 72 VGPRs, as in rounds 3-4)
     const Affine* __restrict__ aff, int num_rois, int height, int width, int pooled_width, int NB,
     int batch_size, unsigned lines_per_roi, PatchMap pm, FastDiv div_pw, KeyLayout L,
     int* __restrict__ cnt, const unsigned* __restrict__ off, const unsigned* __restrict__ bsum,
     uint2* __restrict__ pairs, int pair_blocks, const float* __restrict__ top_diff,
     float* __restrict__ tdT, int C, int nchunks, int ptiles, int relayout_blocks, int tile_begin,
     int tile_end, unsigned scan_blocks, int raw_bsum, BucketLists bl = BucketLists{0u, nullptr, nullptr, nullptr},
-    int skip_dead_bins = 1)
+    int skip_dead_bins = 1)   // flags: bit 0 dead bins are not copied, bit 1 the pair blocks aggregate their reservations per wave
 {
     __shared__ __attribute__((aligned(16))) float T[kChunk * kTP];
+    static_assert(4 * kAggWords <= kChunk * kTP, "the four waves' aggregation tables live in the relayout tile");
     if ((int)blockIdx.x < pair_blocks) {
         if (MODE == 1) bsum = block_prefix(bsum, scan_blocks, raw_bsum != 0, reinterpret_cast<unsigned*>(T));
         const unsigned total = (unsigned)num_rois * pm.lanes_per_roi;
         for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += (unsigned)pair_blocks * 256u)
             pairs_body<MODE>(idx, aff, num_rois, height, width, NB / pooled_width, pooled_width, batch_size,
-                             lines_per_roi, pm, L, cnt, off, bsum, pairs, bl);
+                             lines_per_roi, pm, L, cnt, off, bsum, pairs, bl,
+                             (skip_dead_bins & 2) ? reinterpret_cast<unsigned*>(T) + (threadIdx.x >> 6) * kAggWords : nullptr);
         return;
     }
     // block j takes the pixel ranges j, j + blocks, ... of [tile_begin, tile_end), all chunks of each
     // (round 4) a bin that enters no list is not copied: the list builder's own verdict, bin by bin
     auto live_bin = [&](int n, unsigned ph, unsigned pw) {
-        if (!skip_dead_bins) return true;   // (the exploration build's A/B arm)
+        if (!(skip_dead_bins & 1)) return true;   // (the exploration build's A/B arm)
         bool any = false;
         bin_pairs(aff[n], ph, pw, height, width, batch_size, L, [&](unsigned, float) { any = true; });
         return any;

@@ -93,3 +93,4 @@ int rroi_align_debug_set_fwd_fused(int on, double fused_min, double tiled_min)
     if (tiled_min > 0) g_tune.fwd_tiled_min_elems = tiled_min;
     return old;
 }
+int rroi_align_debug_set_bwd_pair_blocks(int v) { const int old = g_tune.bwd_pair_blocks_per_cu; g_tune.bwd_pair_blocks_per_cu = v; return old; }
