@@ -156,6 +156,29 @@ def train_regime(ext, dev, event_loop):
                 if st != 1:
                     raise RuntimeError(f"train_regime backward -> {st}")
             f_ms, b_ms = event_loop(fwd, 50, 200), event_loop(bwd, 20, 100)
+            # the same pair with channels-last tensors at both ends (what the callers' modules hand over when the backbone
+            # runs channels_last): features consumed in place, crops / gradients channels-last
+            feats_cl = feats.contiguous(memory_format=torch.channels_last)
+            out_cl = torch.empty((R, C, 11, PW), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
+            gout_cl = gout.contiguous(memory_format=torch.channels_last)
+            nf_cl = ext._lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, ext.LAYOUT_NHWC)
+            ws_cl = torch.empty(max(nf_cl, nb, 1), dtype=torch.uint8, device=dev)
+
+            def fwd_cl():
+                st = ext._lib.rroi_align_forward_layout_hip(feats_cl.data_ptr(), ext.LAYOUT_NHWC, ext.LAYOUT_NHWC, scale, B, R, H, W, C,
+                                                            11, PW, rois.data_ptr(), out_cl.data_ptr(), ws_cl.data_ptr(), nf_cl,
+                                                            ext.PATH_AUTO, stream)
+                if st != 1:
+                    raise RuntimeError(f"train_regime forward (channels-last) -> {st}")
+
+            def bwd_cl():
+                st = ext._lib.rroi_align_backward_layout_hip(gout_cl.data_ptr(), ext.LAYOUT_NHWC, ext.LAYOUT_NHWC, scale, B, R, H, W, C,
+                                                             11, PW, rois.data_ptr(), gin.data_ptr(), ws_cl.data_ptr(), nb,
+                                                             ext.PATH_AUTO, stream)
+                if st != 1:
+                    raise RuntimeError(f"train_regime backward (channels-last) -> {st}")
+            fcl_ms, bcl_ms = event_loop(fwd_cl, 50, 200), event_loop(bwd_cl, 20, 100)
+            del feats_cl, out_cl, gout_cl, ws_cl
             # algorithmic bytes: crops + rois + the map once (an upper bound of the touched pixels; at R = 32 most of the
             # map is not touched, so the forward's fraction is an overestimate there -- the call still relays it out)
             crops, fmap = R * C * 11 * PW * 4, B * C * H * W * 4
@@ -164,7 +187,9 @@ def train_regime(ext, dev, event_loop):
                 "forward_us": round(f_ms * 1e3, 2), "backward_us": round(b_ms * 1e3, 2),
                 "forward_algorithmic_bytes": fb, "backward_algorithmic_bytes": bb,
                 "forward_frac_of_peak": round(fb / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "backward_frac_of_peak": round(bb / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                "backward_frac_of_peak": round(bb / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "forward_us_channels_last": round(fcl_ms * 1e3, 2), "backward_us_channels_last": round(bcl_ms * 1e3, 2),
+                "backward_frac_of_peak_channels_last": round(bb / (bcl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del feats, rois, out, gout, gin, ws
     for PW in (83, 100):
         for R in (32, 512):
@@ -173,7 +198,8 @@ def train_regime(ext, dev, event_loop):
     rows["what"] = ("the reference's training call (src/ocr_process.py:259-267): %d images of %d x %d x %d, pooled 11 x PW, "
                     "R ROIs over the images, PATH_AUTO, 200 / 100 back-to-back calls between HIP events; bytes = crops + "
                     "rois + the whole map once; forward_vs_aligned_11x96 = time per output byte against the 11 x 96 shape "
-                    "(rows of whole 64-byte sectors) at the same R" % (B, C, H, W))
+                    "(rows of whole 64-byte sectors) at the same R; *_channels_last = the same calls with channels-last features, crops "
+                    "and gradients (no relayout on either side)" % (B, C, H, W))
     return rows
 
 
@@ -462,6 +488,42 @@ def run(args):
         rois.copy_(keep)
         del keep
 
+    # what ONE call costs when it is not the 1,000th of a back-to-back run -- after >= 2 ms of an
+    # idle GPU and after unrelated kernels (an elementwise pass over 64 MB and a 2048^3 matrix product) have had the caches:
+    # one HIP event before and one after the single call (the pair costs ~2-3 us of its own: it brackets an EMPTY stream at
+    # the `empty_pair_ms` figure)
+    isolated = None
+    if world == 1 and os.environ.get("RROI_BENCH_SENSITIVITY", "1") == "1":
+        other_a = torch.randn(16 << 20, dtype=torch.float32, device=dev)
+        other_m = torch.randn(2048, 2048, dtype=torch.float32, device=dev)
+
+        def one_call(idle, unrelated, empty=False):
+            if unrelated:
+                torch.mul(other_a, 1.0001, out=other_a)
+                torch.mm(other_m, other_m)
+            torch.cuda.synchronize()
+            if idle:
+                time.sleep(0.002)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if not empty:
+                launch(ext.STAGE_ALL)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+        def stats(v):
+            v = sorted(v)
+            return {"median": round(v[len(v) // 2], 5), "min": round(v[0], 5), "max": round(v[-1], 5), "n": len(v)}
+        isolated = {"after_idle_ms": stats([one_call(True, False) for _ in range(15)]),
+                    "after_unrelated_kernels_ms": stats([one_call(False, True) for _ in range(15)]),
+                    "after_idle_and_unrelated_kernels_ms": stats([one_call(True, True) for _ in range(15)]),
+                    "empty_pair_ms": stats([one_call(False, False, empty=True) for _ in range(15)]),
+                    "what": "ONE forward call (prologue + gather, configs[1]) between two HIP events: after 2 ms of idle GPU; "
+                            "right after unrelated kernels (an elementwise pass over 64 MB, a 2048^3 product); after both. "
+                            "empty_pair_ms = the two events with nothing between them. `value` is the steady state of a "
+                            "back-to-back run; this is what a call costs in the middle of other work"}
+        del other_a, other_m
+
     # on the side (not part of `value`): the same call when the producer hands over channels-last
     # features -- consumed in place, no relayout
     nhwc_ms = None
@@ -676,6 +738,7 @@ def run(args):
         "cpu_baseline": cpu,
         "extra": {
             "sensitivity": sensitivity,
+            "isolated_call_ms": isolated,
             "ranks": ranks_info,
             "with_gather_ms": None if with_gather_ms is None else round(with_gather_ms, 4),
             "with_allreduce_grad_ms": None if with_allreduce_ms is None else round(with_allreduce_ms, 4),

@@ -689,13 +689,13 @@ int main(int argc, char** argv)
         rroi_align_debug_set_prologue_blocks(3);
         for (int rep = 0; rep < 5; ++rep)
             for (int paux : {0, 16}) {   // A/B/A/B: is the write-through prologue better over the whole step?
-                rroi_align_debug_set_prologue_aux(paux);
+    // (the prologue store-policy knob went with round 5: plain stores ship)
                 char nm[96];
                 snprintf(nm, 96, "A/B %d: whole step, prologue aux=%d, 50 x 20 steps", rep, paux);
                 report(nm, T.us([&] { for (int i = 0; i < 20; ++i) stage(3); }, 50, 5) / 20, MB);
             }
         for (int paux : {0, 16}) {
-            rroi_align_debug_set_prologue_aux(paux);
+    // (the prologue store-policy knob went with round 5: plain stores ship)
             for (int bpc : {3}) {
                 rroi_align_debug_set_prologue_blocks(bpc);
                 char nm[96];
@@ -796,7 +796,7 @@ int main(int argc, char** argv)
     stage(3);
     CK(hipDeviceSynchronize());
     for (int paux : {0, 2, 16}) {
-        rroi_align_debug_set_prologue_aux(paux);
+    // (the prologue store-policy knob went with round 5: plain stores ship)
         char nm[96];
         snprintf(nm, 96, "product prologue aux=%d warm", paux);
         report(nm, T.us([&] { stage(1); }), 52.4);
@@ -811,9 +811,9 @@ int main(int argc, char** argv)
         snprintf(nm, 96, "pipeline step (20 back-to-back), prologue aux=%d", paux);
         report(nm, pipe, MB);
     }
-    rroi_align_debug_set_prologue_aux(0);
+    // (the prologue store-policy knob went with round 5: plain stores ship)
     rroi_align_debug_set_prologue_blocks(3);
-    rroi_align_debug_set_prologue_aux(0);
+    // (the prologue store-policy knob went with round 5: plain stores ship)
     for (int wpc : {10, 12}) {
         rroi_align_debug_set_split_wgs_per_cu(wpc);
         char nm[96];
