@@ -55,7 +55,7 @@ for t in range(trials):
     want = O.forward_c(f, r_o, ph, pw, s, threads=16)
     want[badb] = 0
     F, Rr = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
-    for p in (ext.PATH_DIRECT, ext.PATH_TILED):
+    for p in (ext.PATH_DIRECT, ext.PATH_TILED, ext.PATH_FUSED, ext.PATH_AUTO):   # (round 5: + the one-launch fused form, AUTO)
         got = ext.forward(F, Rr, ph, pw, s, path=p).cpu().numpy()
         nb = int((~((got == want) | (np.isnan(got) & np.isnan(want)))).sum())
         if nb:
