@@ -92,10 +92,13 @@ struct Tuning {
     int shift_wgs_per_cu = 0;     // > 0 overrides the SHIFT kernels' workgroups per CU
     int fwd_dbg = 0;              // ablations: 1 = skip output stores, 2 = all taps out of range, 256 = free first item
     int prologue_blocks_per_cu = 3;
+    int fwd_patch = 1;            // the direct path = K2p (round 5: shared geometry, row pairs as 8-byte loads); 0: rounds 1-4's thread-per-bin kernel
+    int fwd_patch_waves = 4096;   // ... channel slabs sized for about this many waves ...
+    int fwd_patch_cwave = 8;      // ... of at most this many channels each
     int fwd_fused = 1;            // AUTO may take the one-launch gather from the NCHW map for few ROIs (round 5)
     double fwd_fused_min_elems = 1.5e6;   // ... from this many output elements up (below: the direct kernel) ...
     int fwd_fused_min_channels = 128;     // ... and this many channels
-    double fwd_tiled_min_elems = 3.0e6;   // ... and the two-launch path from this many up
+    double fwd_tiled_min_elems = 3.8e6;   // ... and the two-launch path from this many up
     int fwd_groups = 1;           // XCD groups for nchunks in {1, 2} (round 5; XcdGroups in rroi_forward_kernels.h); 0: off
     int fwd_groups_min_rois = 64; // ... from this many ROIs up
     int bwd_buckets = 1;          // one-pass pixel lists (round 3); 0: count / scan / fill as in rounds 1-2
@@ -167,6 +170,32 @@ void direct_grid(int num_rois, int NB, int channels, dim3& grid, int& cslab)
     while ((long)bx * slabs < target && channels / (slabs * 2) >= 4) slabs *= 2;
     cslab = ceil_div(channels, slabs);
     grid = dim3(bx, ceil_div(channels, cslab), 1);
+}
+
+// K2p, the direct path (rroi_fwd_patch_kernel): workgroup = (ROI, patch of 4 x 16 bins, four channel slabs of `cw` channels).
+// Returns false where the form does not apply (the caller falls back to rounds 1-4's thread-per-bin kernel).
+bool launch_patch_forward(const float* features, const float* rois, float* top_data, float* idx_x, float* idx_y, int num_rois,
+                          int channels, int height, int width, int pooled_height, int pooled_width, float spatial_scale, int trig,
+                          int batch_size, hipStream_t stream)
+{
+    const long NB = (long)pooled_height * pooled_width;
+    if (!g_tune.fwd_patch || width < 2 || (long)num_rois * ceil_div(NB, 16) >= (1L << 30)) return false;
+    const int npx = ceil_div(pooled_width, 16), npatches = ceil_div(pooled_height, 4) * npx;
+    long slabs = ceil_div((long)g_tune.fwd_patch_waves, (long)num_rois * npatches);
+    if (slabs < 1) slabs = 1;
+    int cw = (ceil_div(channels, slabs) + 3) / 4 * 4;
+    if (cw > g_tune.fwd_patch_cwave) cw = g_tune.fwd_patch_cwave;
+    const dim3 pgrid((unsigned)((long)num_rois * npatches), (unsigned)ceil_div(channels, 4 * cw), 1);
+    if (pgrid.y > 65535u) return false;
+    // (tools/patch_sweep.py: 2-8 K waves, 8-32 channels per wave, 4 or 8 in flight -- all within 0.3 us)
+    if (idx_x)
+        hipLaunchKernelGGL((rroi_fwd_patch_kernel<4, true>), pgrid, dim3(256), 0, stream, features, rois, top_data, num_rois, channels,
+                           height, width, pooled_height, pooled_width, spatial_scale, trig, batch_size, cw, npx, npatches, idx_x, idx_y);
+    else
+        hipLaunchKernelGGL((rroi_fwd_patch_kernel<4, false>), pgrid, dim3(256), 0, stream, features, rois, top_data, num_rois, channels,
+                           height, width, pooled_height, pooled_width, spatial_scale, trig, batch_size, cw, npx, npatches,
+                           (float*)nullptr, (float*)nullptr);
+    return true;
 }
 
 FastDiv make_fastdiv(unsigned d)
@@ -326,12 +355,13 @@ BwdWorkspace carve_bwd(void* ws, int batch_size, int channels, int height, int w
     return w;
 }
 
-// AUTO.  The tiled paths have a fixed cost (forward: two launches, ~16 us wall; backward: eight,
-// ~35 us) plus a term in the size of the whole map (relayout; the backward also visits every
-// pixel); the direct paths cost per output element, the backward's with four float atomics.
-// Measured crossovers (tools/crossover.py, MI355X, wall time per call):
-//   forward   C=256 160x160 8x64:  R=16 direct 20 / tiled 17.5,  R=32 40 / 17.5,  R=512 579 / 58
-//             C=64 176x320 11x96:  R=32 direct 13 / tiled 16,    R=64 21 / 17,    R=512 155 / 37
+// AUTO.  The tiled paths have a fixed cost (forward: two launches; backward: three) plus a term in the size of the
+// whole map (relayout; the backward also visits every pixel); the direct paths cost per output element, the
+// backward's with four float atomics.
+// Measured crossovers (MI355X; forward: round 5, tools/fused_probe.py, us per call between events, direct = K2p):
+//   forward   C=64 two 120x160 maps 11x96:  R=32 direct 8.8 / tiled 12.1,  R=48 12.7 / 13.4,  R=64 13.5 / 13.0,  R=128 21.9 / 14.9
+//             C=256 160x160 8x64:  R=8 direct 6.1 / fused 7.3 / tiled 13.9,  R=16 11.5 / 9.7 / 14.4,  R=32 22.1 / 16.0 / 15.5
+//   (rounds 1-4, tools/crossover.py, wall time per call:)
 //   backward  C=256:  R=4 direct 59 / tiled 43,   R=32 448 / 50,   R=512 7145 / 195
 //             C=64:   R=4 direct 15 / tiled 34,   R=16 105 / 39,   R=512 1745 / 113
 bool pick_tiled_fwd(int batch_size, int channels, int height, int width, int num_rois, int NB)
@@ -681,6 +711,9 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
 
     if (!tiled) {
         if (!(stages & RROI_STAGE_GATHER)) return 1;  // the direct path has no prologue
+        if (launch_patch_forward(features, rois, top_data, nullptr, nullptr, num_rois, channels, height, width, pooled_height,
+                                 pooled_width, spatial_scale, trig, batch_size, stream))
+            return launch_status();
         dim3 grid;
         int cslab;
         direct_grid(num_rois, NB, channels, grid, cslab);
@@ -1267,6 +1300,9 @@ int RROIAlignForwardLaucher(const float* bottom_data, const float spatial_scale,
     int cslab;
     direct_grid(num_rois, NB, channels, grid, cslab);
     if (!pick_tiled_fwd(1, channels, height, width, num_rois, NB)) {
+        if (launch_patch_forward(bottom_data, bottom_rois, top_data, con_idx_x, con_idx_y, num_rois, channels, height, width,
+                                 pooled_height, pooled_width, spatial_scale, launcher_trig(), /*batch_size unknown*/ -1, stream))
+            return launch_status();
         hipLaunchKernelGGL(rroi_fwd_direct_kernel, grid, dim3(256), 0, stream, bottom_data, bottom_rois,
                            top_data, con_idx_x, con_idx_y, num_rois, channels, height, width,
                            pooled_height, pooled_width, spatial_scale, launcher_trig(), /*batch_size unknown*/ -1,

@@ -1018,6 +1018,129 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
                min(C, c_begin + cslab));
 }
 
+// ------------------------------------------------------------------------------------
+// K2p (round 5): the lean ONE-LAUNCH forward for few ROIs at few channels -- the reference's own call: <= 32 ROIs per
+// training step on its 64-channel map (src/ocr_process.py:253-267), 1 ... 24 per image in inference.  K2 above pays the
+// double-precision affine and the whole bin geometry per thread and 4-16 channels, and five vector-memory instructions
+// (four taps, one store) plus ~45 VALU per 64 bin-channels: it runs at the VALU and address rates
+// (profiles/r05_small_r_forward.md).  Here:
+//   * workgroup = (ROI, one PATCH of 4 x 16 bins, four channel slabs); the first wave computes what does not depend on the
+//     channel ONCE -- affine, bin centres, tap offsets, validity -- and leaves a 32-byte record per bin in LDS;
+//   * the taps of a bin are whole pixels at (y0 | y1, x0 | x0 + 1): the two pixels of a map ROW come with ONE 8-byte load
+//     (dword-aligned: gfx950 runs with unaligned access enabled), so a bin costs two loads per channel instead of four.
+//     A pair starts at x0 -- or at x0 - 1 when x0 is the row's last pixel, so that it never leaves the plane; a row none
+//     of whose two pixels is a valid tap of its own (kernel.cu:116-126) is the out-of-range offset, which costs no access;
+//   * lane = bin: the stores are rows of 16 consecutive floats of the crop (the crops of few ROIs stay in the L2s until the
+//     launch ends, which merges rows that are not whole sectors).
+// Same arithmetic as every other forward path: blend1 on the reference's four taps in its order.
+// ------------------------------------------------------------------------------------
+struct PatchRec {     // per bin, written by the first wave
+    unsigned o_top, o_bot;   // byte offsets of the row pairs inside a channel plane, or kOOB
+    unsigned flags;          // kV00.. kV11 | kDx | kDy | kActive | kPairShift (the pair starts at x0 - 1)
+    float rx, ry;
+    float cx, cy;            // WITH_IDX: the bin centre the reference ABI's con_idx_x / con_idx_y hold (0 where masked)
+};
+constexpr unsigned kPairShift = 1u << 20;
+
+// WITH_IDX: also the reference ABI's con_idx_x / con_idx_y (kernel.cu:144-145); batch_size < 0 = unknown (that ABI): the
+// image index is trusted as the reference trusts it.
+template <int U, bool WITH_IDX = false>
+__global__ __launch_bounds__(256) void rroi_fwd_patch_kernel(
+    const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out, int num_rois, int C, int height,
+    int width, int pooled_height, int pooled_width, float spatial_scale, int trig, int batch_size, int cwave, int npx,
+    int npatches, float* __restrict__ idx_x = nullptr, float* __restrict__ idx_y = nullptr)
+{
+    __shared__ PatchRec rec[kWave];
+    __shared__ int s_batch;
+    const int n = (int)blockIdx.x / npatches, patch = (int)blockIdx.x - n * npatches;
+    // (the wave index as a SCALAR: the channel planes' buffer descriptors derive from it -- left in a VGPR the compiler
+    // wraps every load in a waterfall loop)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
+    const int py = patch / npx, px = patch - py * npx;
+    const int ph = py * 4 + (lane >> 4), pw = px * 16 + (lane & 15);
+    const bool inside = ph < pooled_height && pw < pooled_width;
+    if (wv == 0) {
+        const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale, trig);
+        float bcx, bcy;
+        const bool in_rroi = bin_centre(A, ph, pw, height, width, bcx, bcy);
+        const bool batch_ok = batch_size < 0 || (A.batch >= 0 && A.batch < batch_size);
+        const bool active = in_rroi && batch_ok && inside;
+        const Taps tp = make_taps(bcx, bcy, active, height, width, 4u);   // byte offsets inside a channel plane
+        const unsigned f = tp.flags;
+        const bool dx = f & kDx, dy = f & kDy;
+        // a row's pair is fetched when one of its two pixels is a valid tap OF ITS OWN (an aliased tap copies)
+        const bool top = (f & kV00) || (dx && (f & kV01));
+        const bool bot = dy && ((f & kV10) || (dx && (f & kV11)));
+        // x0 is the row's last pixel: the pair starts one pixel earlier (x1 = W is never a valid tap)
+        const bool shift = (f & kActive) && f2i_sat(floorf(bcx)) == width - 1 && width >= 2;
+        const unsigned o0 = tp.o_lt - (shift ? 4u : 0u);
+        PatchRec r;
+        r.o_top = top ? o0 : kOOB;
+        r.o_bot = bot ? o0 + (unsigned)width * 4u : kOOB;
+        r.flags = f | (shift ? kPairShift : 0u);
+        r.rx = tp.rx;
+        r.ry = tp.ry;
+        r.cx = (in_rroi && batch_ok) ? bcx : 0.0f;
+        r.cy = (in_rroi && batch_ok) ? bcy : 0.0f;
+        rec[lane] = r;
+        if (lane == 0) s_batch = batch_ok ? A.batch : 0;
+    }
+    __syncthreads();
+    const int c_begin = ((int)blockIdx.y * 4 + wv) * cwave;
+    if (c_begin >= C) return;
+    const int c_end = min(C, c_begin + cwave);
+    const PatchRec r = rec[lane];
+    const int batch = __builtin_amdgcn_readfirstlane(s_batch);
+    const unsigned f = r.flags;
+    const bool act = f & kActive, dx = f & kDx, dy = f & kDy, sh = f & kPairShift;
+    const bool v00 = f & kV00, v01 = f & kV01, v10 = f & kV10, v11 = f & kV11;
+    float wlt, wrt, wrb, wlb;
+    tap_weights(r.rx, r.ry, wlt, wrt, wrb, wlb);
+    const int NB = pooled_height * pooled_width;
+    const size_t HW = (size_t)height * width;
+    const unsigned plane_bytes = (unsigned)(HW * 4u);
+    const float* plane = feat + ((size_t)batch * C + c_begin) * HW;
+    const size_t o0 = ((size_t)n * C + c_begin) * NB + (size_t)ph * pooled_width + pw;
+    float* op = out + o0;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    auto pair = [&](const float* pl, unsigned o) -> v2f {
+        return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(pl, plane_bytes), o, 0, 0));
+    };
+    auto sample = [&](v2f t, v2f b) -> float {
+        // the reference's four taps (kernel.cu:110-126) out of the two pairs: element 0 is x0 (element 1 when the pair was
+        // shifted), the other one x0 + 1; an invalid tap is 0.0, an aliased tap IS the tap it aliases
+        const float lt = v00 ? (sh ? t.y : t.x) : 0.0f;
+        const float rt = dx ? (v01 ? t.y : 0.0f) : lt;
+        const float lb = dy ? (v10 ? (sh ? b.y : b.x) : 0.0f) : lt;
+        const float rb = dx ? (dy ? (v11 ? b.y : 0.0f) : rt) : lb;
+        return act ? blend1(lt, rt, rb, lb, wlt, wrt, wrb, wlb) : 0.0f;
+    };
+    int c = c_begin;
+    for (; c + U <= c_end; c += U, plane += U * HW, op += U * (size_t)NB) {
+        v2f t[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            t[u] = pair(plane + (size_t)u * HW, r.o_top);
+            b[u] = pair(plane + (size_t)u * HW, r.o_bot);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float v = sample(t[u], b[u]);
+            if (inside) op[(size_t)u * NB] = v;
+        }
+    }
+    for (; c < c_end; ++c, plane += HW, op += NB) {
+        const float v = sample(pair(plane, r.o_top), pair(plane, r.o_bot));
+        if (inside) *op = v;
+    }
+    if (WITH_IDX && inside) {
+        for (int cc = 0; cc < c_end - c_begin; ++cc) {
+            __builtin_nontemporal_store(r.cx, idx_x + o0 + (size_t)cc * NB);
+            __builtin_nontemporal_store(r.cy, idx_y + o0 + (size_t)cc * NB);
+        }
+    }
+}
+
 // con_idx_x / con_idx_y of the reference ABI (kernel.cu:144-145): the bin centre of (roi, ph, pw)
 // replicated over the C channels, 0 where the bin is masked.  thread = (roi, bin), loops a channel
 // slab; consecutive lanes write consecutive bins.

@@ -40,7 +40,8 @@ for (B, C, H, W, R, ph, pw) in shapes:
     def call(path):
         assert lib.rroi_align_forward_hip(F.data_ptr(), 0, 0.25, B, R, H, W, C, ph, pw, Rt.data_ptr(), top.data_ptr(), ws.data_ptr(), nb, path, st) == 1
     outs, row = [], []
-    for name, path in (("direct", 1), ("fused", 7), ("tiled", 2), ("auto", 0)):
+    for name, path in (("old", 1), ("direct", 1), ("fused", 7), ("tiled", 2), ("auto", 0)):
+        lib.rroi_align_debug_set_fwd_patch(0 if name == "old" else 1, 0, 0)   # old = rounds 1-4's thread-per-bin kernel
         top.fill_(float("nan"))
         call(path)
         outs.append(top.clone())

@@ -94,3 +94,12 @@ int rroi_align_debug_set_fwd_fused(int on, double fused_min, double tiled_min)
     return old;
 }
 int rroi_align_debug_set_bwd_pair_blocks(int v) { const int old = g_tune.bwd_pair_blocks_per_cu; g_tune.bwd_pair_blocks_per_cu = v; return old; }
+// the direct path's form: 1 = K2p (patch kernel, round 5), 0 = rounds 1-4's thread-per-bin kernel; waves / cwave: 0 = leave
+int rroi_align_debug_set_fwd_patch(int on, int waves, int cwave)
+{
+    const int old = g_tune.fwd_patch;
+    g_tune.fwd_patch = on;
+    if (waves > 0) g_tune.fwd_patch_waves = waves;
+    if (cwave > 0) g_tune.fwd_patch_cwave = cwave;
+    return old;
+}
