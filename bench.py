@@ -488,42 +488,6 @@ def run(args):
         rois.copy_(keep)
         del keep
 
-    # VERDICT r04 item 6(ii): what ONE call costs when it is not the 1,000th of a back-to-back run -- after >= 2 ms of an
-    # idle GPU and after unrelated kernels (an elementwise pass over 64 MB and a 2048^3 matrix product) have had the caches:
-    # one HIP event before and one after the single call (the pair costs ~2-3 us of its own: it brackets an EMPTY stream at
-    # the `empty_pair_ms` figure)
-    isolated = None
-    if world == 1 and os.environ.get("RROI_BENCH_SENSITIVITY", "1") == "1":
-        other_a = torch.randn(16 << 20, dtype=torch.float32, device=dev)
-        other_m = torch.randn(2048, 2048, dtype=torch.float32, device=dev)
-
-        def one_call(idle, unrelated, empty=False):
-            if unrelated:
-                torch.mul(other_a, 1.0001, out=other_a)
-                torch.mm(other_m, other_m)
-            torch.cuda.synchronize()
-            if idle:
-                time.sleep(0.002)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            if not empty:
-                launch(ext.STAGE_ALL)
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1)
-        def stats(v):
-            v = sorted(v)
-            return {"median": round(v[len(v) // 2], 5), "min": round(v[0], 5), "max": round(v[-1], 5), "n": len(v)}
-        isolated = {"after_idle_ms": stats([one_call(True, False) for _ in range(15)]),
-                    "after_unrelated_kernels_ms": stats([one_call(False, True) for _ in range(15)]),
-                    "after_idle_and_unrelated_kernels_ms": stats([one_call(True, True) for _ in range(15)]),
-                    "empty_pair_ms": stats([one_call(False, False, empty=True) for _ in range(15)]),
-                    "what": "ONE forward call (prologue + gather, configs[1]) between two HIP events: after 2 ms of idle GPU; "
-                            "right after unrelated kernels (an elementwise pass over 64 MB, a 2048^3 product); after both. "
-                            "empty_pair_ms = the two events with nothing between them. `value` is the steady state of a "
-                            "back-to-back run; this is what a call costs in the middle of other work"}
-        del other_a, other_m
-
     # on the side (not part of `value`): the same call when the producer hands over channels-last
     # features -- consumed in place, no relayout
     nhwc_ms = None
@@ -568,6 +532,42 @@ def run(args):
                 raise RuntimeError(f"rroi_align_backward_layout_hip -> {st}")
         bwd_cl_ms = event_loop(bwd_cl, 10, 50)
         del gout, gout_cl, ws_b, gin
+
+    # VERDICT r04 item 6(ii): what ONE call costs when it is not the 1,000th of a back-to-back run -- after >= 2 ms of an
+    # idle GPU and after unrelated kernels (an elementwise pass over 64 MB and a 2048^3 matrix product) have had the caches:
+    # one HIP event before and one after the single call (the pair costs ~2-3 us of its own: it brackets an EMPTY stream at
+    # the `empty_pair_ms` figure)
+    isolated = None
+    if world == 1 and os.environ.get("RROI_BENCH_SENSITIVITY", "1") == "1":
+        other_a = torch.randn(16 << 20, dtype=torch.float32, device=dev)
+        other_m = torch.randn(2048, 2048, dtype=torch.float32, device=dev)
+
+        def one_call(idle, unrelated, empty=False):
+            if unrelated:
+                torch.mul(other_a, 1.0001, out=other_a)
+                torch.mm(other_m, other_m)
+            torch.cuda.synchronize()
+            if idle:
+                time.sleep(0.002)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if not empty:
+                launch(ext.STAGE_ALL)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+        def stats(v):
+            v = sorted(v)
+            return {"median": round(v[len(v) // 2], 5), "min": round(v[0], 5), "max": round(v[-1], 5), "n": len(v)}
+        isolated = {"after_idle_ms": stats([one_call(True, False) for _ in range(15)]),
+                    "after_unrelated_kernels_ms": stats([one_call(False, True) for _ in range(15)]),
+                    "after_idle_and_unrelated_kernels_ms": stats([one_call(True, True) for _ in range(15)]),
+                    "empty_pair_ms": stats([one_call(False, False, empty=True) for _ in range(15)]),
+                    "what": "ONE forward call (prologue + gather, configs[1]) between two HIP events: after 2 ms of idle GPU; "
+                            "right after unrelated kernels (an elementwise pass over 64 MB, a 2048^3 product); after both. "
+                            "empty_pair_ms = the two events with nothing between them. `value` is the steady state of a "
+                            "back-to-back run; this is what a call costs in the middle of other work"}
+        del other_a, other_m
 
     train = None
     if world == 1 and os.environ.get("RROI_BENCH_TRAIN", "1") == "1":

@@ -1012,6 +1012,9 @@ static int backward_impl(const float* top_diff, int top_diff_layout, int bottom_
             // 59.7 / 59.7; configs[2]: 104.4 / 103.3 / 103.6 / 103.5)
             int per_cu = g_tune.bwd_pair_blocks_per_cu;
             if (per_cu <= 0) per_cu = std::min(4, std::max(2, 256 / std::max(channels, 1)));
+            // channels-last gradients need no relayout: the pair blocks have the launch to themselves (CL=1 tools/pair_blocks_ab.py,
+            // profiles/r05_pair_blocks_ab_cl.txt: C = 64, R = 512 45.3 / 41.4 us at 4 / 8 per CU, round 4: 64.0; configs[2] 52.8 / 49.0, 51.3)
+            if (g_tune.bwd_pair_blocks_per_cu <= 0 && td_nhwc) per_cu = 8;
             const long cap = (long)num_cus() * per_cu;
             if (pblocks > cap) pblocks = (int)cap;
         }

@@ -199,6 +199,23 @@ __device__ __forceinline__ void pairs_body(unsigned idx, const Affine* __restric
     const unsigned pw = (px << pm.pc_shift) + (l & ((1u << pm.pc_shift) - 1u));
     const bool has_bin = n < (unsigned)num_rois && ph < (unsigned)pooled_height && pw < (unsigned)pooled_width;
     const unsigned j = ph * (unsigned)pooled_width + pw;
+    if (MODE == 2 && !agg) {
+        // few patches per wave: one returning atomic per pair as it is found, no table to set up
+        if (!has_bin) return;
+        const Affine A = aff[n];
+        bin_pairs(A, ph, pw, height, width, batch_size, L, [&](unsigned key, float w) {
+            const unsigned slot = (unsigned)atomicAdd(cnt + key, 1);
+            const uint2 rec = make_uint2(n * lines_per_roi + j, as_u(w));
+            if (slot < (1u << bl.kshift)) {
+                pairs[((size_t)key << bl.kshift) + slot] = rec;
+            } else {
+                const unsigned e = atomicAdd(bl.ovcnt, 1u);
+                const int prev = atomicExch(bl.head + key, (int)e);
+                bl.ov[e] = make_uint4(rec.x, rec.y, (unsigned)prev, 0u);
+            }
+        });
+        return;
+    }
     if (MODE == 2) {
         // every lane of the wave gets here: the slots are reserved by the wave as a whole (pairs_reserve_wave)
         unsigned keys[4] = {0u, 0u, 0u, 0u}, np = 0u, slots[4] = {0u, 0u, 0u, 0u};
@@ -213,13 +230,7 @@ __device__ __forceinline__ void pairs_body(unsigned idx, const Affine* __restric
                 ++np;
             });
         }
-        if (agg) {
-            pairs_reserve_wave(agg, keys, np, cnt, slots);
-        } else {   // few patches per wave: one returning atomic per pair, no table to set up
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                if ((unsigned)p < np) slots[p] = (unsigned)atomicAdd(cnt + keys[p], 1);
-        }
+        pairs_reserve_wave(agg, keys, np, cnt, slots);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             if ((unsigned)p >= np) continue;

@@ -15,13 +15,15 @@ if which == "prev":
     lib.rroi_align_backward_hip.argtypes = ext._lib.rroi_align_backward_hip.argtypes
     lib.rroi_align_backward_workspace_bytes.restype = ctypes.c_size_t
     lib.rroi_align_backward_workspace_bytes.argtypes = [ctypes.c_int] * 7
-f, r = Wk.bench_inputs(R=R)
+TRAIN = os.environ.get("TRAIN") == "1"   # the training shape instead of configs[2]
+B, C, H, W, PH, PW = (2, 64, 120, 160, 11, 96) if TRAIN else (1, 256, 160, 160, 8, 64)
+f, r = Wk.bench_inputs(R=R, C=C, H=H, W=W, img=4 * W, batch=B)
 Rt = torch.from_numpy(r).cuda()
-g = torch.randn(R, 256, 8, 64, device="cuda")
+g = torch.randn(R, C, PH, PW, device="cuda")
 gin = torch.empty(f.shape, device="cuda")
-nb = lib.rroi_align_backward_workspace_bytes(1, 256, 160, 160, R, 8, 64)
+nb = lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, PH, PW)
 ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(40):
-    assert lib.rroi_align_backward_hip(g.data_ptr(), 0.25, 1, R, 160, 160, 256, 8, 64, Rt.data_ptr(), gin.data_ptr(), ws.data_ptr(), nb, 0, st) == 1
+    assert lib.rroi_align_backward_hip(g.data_ptr(), 0.25, B, R, H, W, C, PH, PW, Rt.data_ptr(), gin.data_ptr(), ws.data_ptr(), nb, 0, st) == 1
 torch.cuda.synchronize()

@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_explore", "librroi_align_hip_explore.so"))
 vp, fl, it, sz = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
 lib.rroi_align_backward_hip.argtypes = [vp, fl, it, it, it, it, it, it, it, vp, vp, vp, sz, it, vp]
+lib.rroi_align_backward_layout_hip.argtypes = [vp, it, it, fl, it, it, it, it, it, it, it, vp, vp, vp, sz, it, vp]
+CL = os.environ.get("CL") == "1"   # channels-last top_diff and bottom_diff (no relayout in the list launch)
 lib.rroi_align_backward_workspace_bytes.restype = sz
 lib.rroi_align_backward_workspace_bytes.argtypes = [it] * 7
 st = torch.cuda.current_stream().cuda_stream
@@ -39,22 +41,34 @@ for (B, C, H, W, R, ph, pw) in shapes:
     gin = torch.empty((B, C, H, W), device="cuda")
     nb = lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, ph, pw)
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    if CL:
+        g = g.contiguous(memory_format=torch.channels_last)
+        gin = gin.contiguous(memory_format=torch.channels_last)
     def call():
-        assert lib.rroi_align_backward_hip(g.data_ptr(), 0.25, B, R, H, W, C, ph, pw, rois.data_ptr(), gin.data_ptr(), ws.data_ptr(), nb, 0, st) == 1
+        if CL:
+            assert lib.rroi_align_backward_layout_hip(g.data_ptr(), 1, 1, 0.25, B, R, H, W, C, ph, pw, rois.data_ptr(), gin.data_ptr(), ws.data_ptr(), nb, 0, st) == 1
+        else:
+            assert lib.rroi_align_backward_hip(g.data_ptr(), 0.25, B, R, H, W, C, ph, pw, rois.data_ptr(), gin.data_ptr(), ws.data_ptr(), nb, 0, st) == 1
     row, ref = [], None
     if prev is not None:
         nbp = prev.rroi_align_backward_workspace_bytes(B, C, H, W, R, ph, pw)
         wsp = torch.empty(nbp, dtype=torch.uint8, device="cuda")
+        prev.rroi_align_backward_layout_hip.argtypes = lib.rroi_align_backward_layout_hip.argtypes
         def callp():
+            if CL:
+                assert prev.rroi_align_backward_layout_hip(g.data_ptr(), 1, 1, 0.25, B, R, H, W, C, ph, pw, rois.data_ptr(), gin.data_ptr(), wsp.data_ptr(), nbp, 0, st) == 1
+                return
             assert prev.rroi_align_backward_hip(g.data_ptr(), 0.25, B, R, H, W, C, ph, pw, rois.data_ptr(), gin.data_ptr(), wsp.data_ptr(), nbp, 0, st) == 1
         callp(); torch.cuda.synchronize()
         ref = gin.clone()
         row.append(f"prev: {timeit(callp):6.1f}")
-    for per in (1, 0, 2, 4, 8, 16):
-        lib.rroi_align_debug_set_bwd_pair_blocks(per)
+    for per in (1, 0, 2, 4, 8, 16, -8):   # (-n: n blocks per CU, one atomic per pair -- no aggregation)
+        lib.rroi_align_debug_set_bwd_pair_aggregate(0 if per < 0 else 1)
+        lib.rroi_align_debug_set_bwd_pair_blocks(abs(per))
         call(); torch.cuda.synchronize()
         if ref is None: ref = gin.clone()
         ok = float((gin - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
         row.append(f"{per if per else 'auto'}: {timeit(call):6.1f}{'' if ok else ' WRONG'}")
     lib.rroi_align_debug_set_bwd_pair_blocks(0)
+    lib.rroi_align_debug_set_bwd_pair_aggregate(1)
     print(f"B={B} C={C:3d} {H}x{W} R={R:4d} {ph}x{pw:3d}  " + "  ".join(row), flush=True)

@@ -103,3 +103,4 @@ int rroi_align_debug_set_fwd_patch(int on, int waves, int cwave)
     if (cwave > 0) g_tune.fwd_patch_cwave = cwave;
     return old;
 }
+int rroi_align_debug_set_bwd_pair_aggregate(int v) { const int old = g_tune.bwd_pair_aggregate; g_tune.bwd_pair_aggregate = v; return old; }

@@ -7,7 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "fots.pytorch_amd"), os.path.join(ROOT,
 import workloads as Wk
 from rroi_align._ext import rroi_align as ext
 st = torch.cuda.current_stream().cuda_stream
-for (R, pw) in ((512, 96), (512, 83), (32, 96)):
+for (R, pw) in ((512, 96), (512, 83), (32, 96), (24, 128)):
     f, r = Wk.bench_inputs(R=R, C=64, H=120, W=160, img=640, seed=3, batch=2)
     F, Rt = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
     out = torch.empty((R, 64, 11, pw), device="cuda")
