@@ -409,8 +409,13 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
     if (!TO_NCHW && !live) return;
     unsigned beg = 0u, end = 0u;
     int chain = -1;   // BUCKET: newest overflow entry of this pixel
+    uint2 rec0 = make_uint2(0u, 0u);   // BUCKET: the lane's record of the bucket's first group, fetched ahead
     if (!live) {
     } else if (BUCKET) {
+        // (round 5) the walk is a chain of dependent round trips: counter -> records -> data.  A bucket's place does not
+        // depend on its counter, so the first group of records is fetched TOGETHER with the counter -- whatever lies
+        // beyond the count is never used -- and the chain is one round trip shorter for every pixel.
+        if (sl < (1u << bl.kshift)) rec0 = pairs[((size_t)key << bl.kshift) + sl];
         const unsigned have = off[key];
         beg = key << bl.kshift;
         end = beg + min(have, 1u << bl.kshift);
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(256) void rroi_bwd_gather_kernel(
             v4f acc = z4;
             for (unsigned base = beg; base < end; base += sub) {
                 const unsigned m = min(sub, end - base);
-                const uint2 rec = sl < m ? pairs[base + sl] : make_uint2(0u, 0u);
+                const uint2 rec = (BUCKET && base == beg) ? rec0 : (sl < m ? pairs[base + sl] : make_uint2(0u, 0u));
                 for (unsigned j = 0; j < m; j += kDepth) {
                     v4f g[kDepth];
                     unsigned wb[kDepth];

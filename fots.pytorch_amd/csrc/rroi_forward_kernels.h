@@ -1024,13 +1024,14 @@ __global__ __launch_bounds__(256) void rroi_fwd_direct_kernel(
 // double-precision affine and the whole bin geometry per thread and 4-16 channels, and five vector-memory instructions
 // (four taps, one store) plus ~45 VALU per 64 bin-channels: it runs at the VALU and address rates
 // (profiles/r05_small_r_forward.md).  Here:
-//   * workgroup = (ROI, one PATCH of 4 x 16 bins, four channel slabs); the first wave computes what does not depend on the
+//   * workgroup = (ROI, one PATCH of up to 64 bins -- 4 x 16, or whatever shape fills the pooled size best --, four channel
+//     slabs); the first wave computes what does not depend on the
 //     channel ONCE -- affine, bin centres, tap offsets, validity -- and leaves a 32-byte record per bin in LDS;
 //   * the taps of a bin are whole pixels at (y0 | y1, x0 | x0 + 1): the two pixels of a map ROW come with ONE 8-byte load
 //     (dword-aligned: gfx950 runs with unaligned access enabled), so a bin costs two loads per channel instead of four.
 //     A pair starts at x0 -- or at x0 - 1 when x0 is the row's last pixel, so that it never leaves the plane; a row none
 //     of whose two pixels is a valid tap of its own (kernel.cu:116-126) is the out-of-range offset, which costs no access;
-//   * lane = bin: the stores are rows of 16 consecutive floats of the crop (the crops of few ROIs stay in the L2s until the
+//   * lane = bin: the stores are rows of a patch's width in consecutive floats of the crop (the crops of few ROIs stay in the L2s until the
 //     launch ends, which merges rows that are not whole sectors).
 // Same arithmetic as every other forward path: blend1 on the reference's four taps in its order.
 // ------------------------------------------------------------------------------------
@@ -1048,7 +1049,7 @@ template <int U, bool WITH_IDX = false>
 __global__ __launch_bounds__(256) void rroi_fwd_patch_kernel(
     const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out, int num_rois, int C, int height,
     int width, int pooled_height, int pooled_width, float spatial_scale, int trig, int batch_size, int cwave, int npx,
-    int npatches, float* __restrict__ idx_x = nullptr, float* __restrict__ idx_y = nullptr)
+    int npatches, int prows, int pcols, float* __restrict__ idx_x = nullptr, float* __restrict__ idx_y = nullptr)
 {
     __shared__ PatchRec rec[kWave];
     __shared__ int s_batch;
@@ -1057,8 +1058,11 @@ __global__ __launch_bounds__(256) void rroi_fwd_patch_kernel(
     // wraps every load in a waterfall loop)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
     const int py = patch / npx, px = patch - py * npx;
-    const int ph = py * 4 + (lane >> 4), pw = px * 16 + (lane & 15);
-    const bool inside = ph < pooled_height && pw < pooled_width;
+    // a patch is prows x pcols bins (prows * pcols <= 64; the host picks the shape that wastes the fewest lanes on this
+    // pooled size: 4 x 16 for 11 x 96, 3 x 21 for 11 x 83), lane = row-major position in it
+    const int lrow = lane / pcols, lcol = lane - lrow * pcols;
+    const int ph = py * prows + lrow, pw = px * pcols + lcol;
+    const bool inside = lrow < prows && ph < pooled_height && pw < pooled_width;
     if (wv == 0) {
         const Affine A = make_affine(rois + (size_t)n * 6, pooled_height, spatial_scale, trig);
         float bcx, bcy;
