@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from rroi_align.batched import rois_from_quads
+from rroi_align.batched import _crops_channels_last, rois_from_quads
 from rroi_align.decode import ctc_greedy_decode
 from rroi_align.modules.rroi_align import _RRoiAlign
 
@@ -83,7 +83,8 @@ def batched(net, converter, features, boxes, return_crops=False, gw_host=None):
         if gw_host.numel() != n:
             raise ValueError("gw_host must have one width per box")
     widths = sorted(set(int(v) for v in gw_host))
-    crops_all = _RRoiAlign(TARGET_H, widths[-1], SPATIAL_SCALE)(focr, rois)
+    # (the crops follow the features' layout: a channels_last network gets channels_last crops, no relayout on either side)
+    crops_all = _RRoiAlign(TARGET_H, widths[-1], SPATIAL_SCALE, _crops_channels_last(focr, None))(focr, rois)
     texts = [None] * n
     crops, labels = [None] * n, [None] * n
     # every bucket's head and decode are enqueued before anything is read back: one wait for the image,
