@@ -120,6 +120,25 @@ def test_forward_xcd_groups(ext, oracle, case):
     assert eq(out.cpu().numpy(), want)
 
 
+def test_forward_tiny_maps_every_path(ext, oracle):
+    """Maps of one to five pixels a side (the direct path's row PAIRS -- 8-byte loads that start at x0, or at x0 - 1 on a
+    row's last pixel -- have nowhere to go wrong but here; a map one pixel wide takes the thread-per-bin fallback), odd
+    channel counts, ROIs larger than the map: every forward path bit-exact against the oracle."""
+    rng = np.random.default_rng(77)
+    for (H, W) in ((1, 1), (1, 2), (2, 1), (2, 2), (2, 3), (3, 2), (5, 4), (4, 5), (1, 7), (7, 1)):
+        for C in (1, 3, 33):
+            f = rng.standard_normal((2, C, H, W), dtype=np.float32)
+            R = 12
+            r = np.stack([rng.integers(0, 2, R), rng.uniform(-1, W + 1, R), rng.uniform(-1, H + 1, R), rng.uniform(0.5, 2 * H + 1, R),
+                          rng.uniform(0.5, 3 * W + 1, R), rng.uniform(-90, 90, R)], 1).astype(np.float32)
+            for (ph, pw) in ((2, 3), (3, 21), (8, 16)):
+                want = oracle.forward_c(f, r, ph, pw, 1.0)
+                for p in ext.FORWARD_PATHS:
+                    got = run_fwd(ext, f, r, ph, pw, 1.0, p)
+                    n, d = mismatch(got, want)
+                    assert n == 0, f"{H}x{W} C={C} {ph}x{pw} path {p}: {n} elements differ, max |d| = {d}"
+
+
 @pytest.mark.parametrize("path", ["direct", "tiled", "fused"])
 def test_forward_edge_and_degenerate_rois(ext, oracle, path):
     rng = np.random.default_rng(1)

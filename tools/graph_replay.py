@@ -44,3 +44,4 @@ def run(name, R, C, H, W, ph, pw, path):
 run("inference, 24 boxes x 64 ch x 11x256, tiled (2 launches)", 24, 64, 176, 320, 11, 256, ext.PATH_TILED)
 run("inference, 24 boxes x 64 ch x 11x256, direct (1 launch)", 24, 64, 176, 320, 11, 256, ext.PATH_DIRECT)
 run("bench shapes, tiled", 512, 256, 160, 160, 8, 64, ext.PATH_TILED)
+run("bench shapes, tiled (again)", 512, 256, 160, 160, 8, 64, ext.PATH_TILED)
