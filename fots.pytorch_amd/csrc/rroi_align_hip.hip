@@ -172,7 +172,7 @@ void direct_grid(int num_rois, int NB, int channels, dim3& grid, int& cslab)
     grid = dim3(bx, ceil_div(channels, cslab), 1);
 }
 
-// K2p, the direct path (rroi_fwd_patch_kernel): workgroup = (ROI, patch of 4 x 16 bins, four channel slabs of `cw` channels).
+// K2p, the direct path (rroi_fwd_patch_kernel): workgroup = (ROI, patch of up to 64 bins, four channel slabs of `cw` channels).
 // Returns false where the form does not apply (the caller falls back to rounds 1-4's thread-per-bin kernel).
 bool launch_patch_forward(const float* features, const float* rois, float* top_data, float* idx_x, float* idx_y, int num_rois,
                           int channels, int height, int width, int pooled_height, int pooled_width, float spatial_scale, int trig,
@@ -388,15 +388,15 @@ bool pick_tiled_fwd(int batch_size, int channels, int height, int width, int num
     const double map_elems = (double)batch_size * channels * height * width;
     return out_elems >= g_tune.fwd_tiled_min_elems && out_elems >= map_elems / 4;
 }
-// Below the two-launch path's crossover: the one-launch gather from the NCHW map (RROI_PATH_FUSED) or the thread-per-bin
-// direct kernel?  Measured (tools/fused_probe.py, profiles/r05_fused_probe.txt; us per call, direct / fused / tiled):
-//   C = 64, two 120 x 160 maps, 11 x 96:  R = 8  5.0 / 6.6 / 10.8,  16  7.4 / 7.9 / 11.0,  32  10.5 / 11.7 / 12.1,  64  16.6 / 17.9 / 13.0
-//   C = 128, 160 x 160, 8 x 64:           R = 32  12.2 / 8.2 / 11.4
-//   C = 256, 160 x 160, 8 x 64:           R = 8  7.0 / 7.4 / 13.9,  16  14.7 / 9.7 / 14.3,  32  35.8 / 16.0 / 15.4
-// Both one-launch forms pay per output element (the direct kernel VALU and address work per bin and channel, the fused
-// one four dword loads per tap) and meet at ~1.5 M elements; the fused form's per-ROI geometry is shared by 32 channels
-// instead of 4-16, so it wins from there up to the two-launch path's crossover WHEN THERE ARE CHANNELS TO SHARE IT: C >= 128.
-// At the reference's own C = 64 the direct kernel stays ahead up to the two-launch path (profiles/r05_small_r_forward.md).
+// Below the two-launch path's crossover: the one-launch gather from the NCHW map (RROI_PATH_FUSED) or the direct path's
+// patch kernel (K2p)?  Measured (tools/fused_probe.py, profiles/r05_fused_probe.txt; us per call, K2p / fused / two-launch):
+//   C = 64, two 120 x 160 maps, 11 x 96:  R = 8  4.9 / 6.4 / 10.9,  16  7.3 / 7.9 / 11.0,  32  8.9 / 11.7 / 12.1,  64  12.7 / 17.9 / 13.0
+//   C = 128, 160 x 160, 8 x 64:           R = 32  10.9 / 8.2 / 11.5
+//   C = 256, 160 x 160, 8 x 64:           R = 8  6.5 / 7.4 / 13.9,  16  11.6 / 9.7 / 14.4,  32  21.0 / 16.1 / 15.5
+// Both one-launch forms pay per output element (K2p three vector-memory instructions and ~16 VALU per 64 bin-channels, the
+// fused form four dword loads per tap but one 16-byte store and one blend per FOUR channels) and meet at ~1.5 M elements;
+// the fused form wins from there up to the two-launch crossover WHEN THERE ARE CHANNELS TO AMORTISE ITS ITEMS OVER: C >= 128.
+// At the reference's own C = 64 K2p stays ahead up to the two-launch path (profiles/r05_small_r_forward.md).
 bool pick_fused_fwd(int batch_size, int channels, int height, int width, int num_rois, int NB)
 {
     (void)batch_size; (void)height; (void)width;
