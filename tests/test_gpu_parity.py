@@ -672,6 +672,45 @@ def test_reference_launchers_reuse_their_scratch_and_accumulate(ext, oracle):
     assert torch.equal(out, want_out)
 
 
+def test_reference_launchers_from_several_threads(ext, oracle):
+    """the launchers' scratch table has one lock per (device, stream) entry (held until the caller has enqueued
+    its launches) and a table lock for look-up only: threads on DIFFERENT streams run concurrently, threads SHARING a
+    stream serialise on its entry -- either way every call gets its own correct crops, through growth of the buffers (the
+    ROI count alternates) and more streams than the table has entries."""
+    import threading
+    f, r = Wk.bench_inputs(R=160, C=64, seed=41)
+    F = dev(f)
+    sizes = (96, 160, 128)
+    want = {n: oracle.forward_c(f, r[:n], 8, 64, 0.25, threads=8) for n in sizes}
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    errors = []
+
+    def worker(tid):
+        try:
+            st_ = streams[tid % len(streams)] if tid < 12 else streams[0]      # the last four threads share one stream
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(st_):
+                for it in range(12):
+                    n = sizes[(tid + it) % len(sizes)]
+                    Rr = dev(r[:n])
+                    out = torch.empty((n, 64, 8, 64), device="cuda")
+                    assert ext._lib.RROIAlignForwardLaucher(F.data_ptr(), 0.25, n, 160, 160, 64, 8, 64, Rr.data_ptr(),
+                                                            out.data_ptr(), None, None, st_.cuda_stream) == 1
+                    st_.synchronize()
+                    if not eq(out.cpu().numpy(), want[n]):
+                        errors.append((tid, it, n))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    ext.release_workspaces()
+
+
 def test_channels_last_odd_chunk(ext, oracle):
     """C % 32 != 0 with channels-last features consumed in place -- the lanes of the
     channel quads beyond C must fetch nothing (their offset is an out-of-range sentinel that may not
