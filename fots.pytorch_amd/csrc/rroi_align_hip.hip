@@ -99,6 +99,7 @@ struct Tuning {
     double fwd_fused_min_elems = 1.5e6;   // ... from this many output elements up (below: the direct kernel) ...
     int fwd_fused_min_channels = 128;     // ... and this many channels
     double fwd_tiled_min_elems = 3.8e6;   // ... and the two-launch path from this many up
+    int fwd_merge = 1;            // rows that are not whole sectors under XCD groups: strided tiles + plain stores where it pays (round 5); 0: SHIFT always; 2: always
     int fwd_groups = 1;           // XCD groups for nchunks in {1, 2} (round 5; XcdGroups in rroi_forward_kernels.h); 0: off
     int fwd_groups_min_rois = 64; // ... from this many ROIs up
     int bwd_buckets = 1;          // one-pass pixel lists (round 3); 0: count / scan / fill as in rounds 1-2
@@ -426,6 +427,7 @@ enum class FwdKernel {
     kStrided,        // every n-th (roi, tile) item per workgroup, 16-byte stores: crops whose rows are whole sectors
     kChannelsLast,   // channels-last crops (R, PH, PW, C)
     kShift,          // SHIFT: overlapped tiles, sector-aligned store windows -- crops whose rows are not whole sectors
+    kStridedMerge,   // strided tiles on rows that are not whole sectors, plain stores: the XCD's L2 merges the partial sectors (XCD groups only)
 };
 struct ForwardPlan {
     FwdKernel kernel;
@@ -437,7 +439,8 @@ struct ForwardPlan {
 constexpr int kShiftWgsPerCu = 12;   // the SHIFT instantiation: <= 80 VGPRs under __launch_bounds__(128, 6), 12.4 KB of LDS
 constexpr int kShiftOwnBins = kTileBins - 16;   // bins a SHIFT tile advances by (it gathers 64: kOwnBins in the kernel)
 
-ForwardPlan plan_forward_gather(int num_rois, int channels, int NB, int nchunks, bool out_nhwc, bool launcher_rest)
+ForwardPlan plan_forward_gather(int num_rois, int channels, int NB, int nchunks, bool out_nhwc, bool launcher_rest, int groups = 1,
+                                size_t map_bytes_per_xcd = 0)
 {
     const int base_dbg = (g_tune.fwd_dbg & ~0xe0) | (launcher_rest ? 32 : 0);   // bits 5-7 are the host's
     const int ntiles = ceil_div(NB, kTileBins);
@@ -448,6 +451,17 @@ ForwardPlan plan_forward_gather(int num_rois, int channels, int NB, int nchunks,
     // like the strided form's.  It costs 4 / 3 of the gather work per byte and was never slower than the strided items on
     // such crops, from R = 8 to R = 2048 (tools/align_probe.py, profiles/r04_align_probe.txt: R = 32, C = 64, 11 x 83: 6.6
     // against 9.4 us; R = 128, 11 x 100: 13.7 against 16.5; R = 512, 11 x 83: 40 against 209)
+    // Round 5, with XCD groups: ALL tiles of a (roi, chunk) block go through ONE XCD at about the same time, so the partial
+    // sectors that strided tiles leave at their ends on rows that are not whole sectors meet in that XCD's L2 -- if the
+    // stores are plain (write-back) instead of streamed.  Then such crops need no SHIFT form (4 / 3 of the items): strided
+    // tiles, 16-byte stores at dword alignment, a row's last <= 3 dwords in its last tile (WAUX = 0 in the kernel).
+    // tools/merge_ab.py, profiles/r05_merge_ab.txt (us per call, SHIFT / merging): C = 64, two 120 x 160 maps, R = 512: 11 x 83
+    // 32.9 / 30.1, 11 x 84 32.2 / 29.6, 11 x 91 34.5 / 33.0, 11 x 100 35.4 / 34.8; C = 32 20.9 / 19.9.  It needs the L2 room:
+    // R = 128 15.7 / 15.6, R = 64 12.5 / 13.1, eight 160 x 160 maps (6.6 MB of map per XCD) 47.1 / 49.8 -- so: XCD groups, at
+    // least 48 MB of crops, at most 2 MB of the chunk-major copy per XCD.
+    if (g_tune.fwd_merge && groups > 1 && NB % 16 != 0 && (g_tune.fwd_merge > 1 ||
+        ((size_t)num_rois * channels * NB * sizeof(float) >= ((size_t)48 << 20) && map_bytes_per_xcd <= ((size_t)2 << 20))))
+        return {FwdKernel::kStridedMerge, tiled_grid((long)num_rois * ntiles, nchunks, g_tune.split_wgs_per_cu), ntiles, base_dbg};
     if (NB % 4 != 0 || (g_tune.fwd_shift && (NB % 16 != 0 || g_tune.fwd_shift == 2))) {   // (rows of dwords: always)
         const int wpc = g_tune.shift_wgs_per_cu > 0 ? g_tune.shift_wgs_per_cu : kShiftWgsPerCu;
         const int nt = ceil_div(NB, kShiftOwnBins);
@@ -780,7 +794,8 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         if (st != 1) return st;
     }
     if (stages & RROI_STAGE_GATHER) {
-        const ForwardPlan plan = plan_forward_gather(num_rois, channels, NB, nchunks, out_nhwc, launcher_rest);
+        const ForwardPlan plan = plan_forward_gather(num_rois, channels, NB, nchunks, out_nhwc, launcher_rest, groups,
+                                                     zero_copy ? (size_t)batch_size * HW * channels * 4 / 8 : ws.cm_bytes / 8);
         const int ntiles = plan.ntiles;
         if ((long)num_rois * ntiles >= (1L << 31)) return 0;
         SliceLayout lay;
@@ -807,6 +822,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         case FwdKernel::kStrided:       RROI_GATHER(true, 0, 6, 3, false, 0); break;   // 62-64 VGPRs, 12.1 KB of LDS: 12 per CU
         case FwdKernel::kChannelsLast:  RROI_GATHER(true, 2, 5, 2, true, 0); break;    // 91 VGPRs: 10 per CU
         case FwdKernel::kShift:         RROI_GATHER(true, 0, 6, 3, false, 1); break;    // 79 VGPRs, 12.4 KB of LDS: 12 per CU
+        case FwdKernel::kStridedMerge:  RROI_GATHER(true, 0, 6, 3, false, 0, false, 0); break;   // plain stores (write-through: 32.1 against 30.1 us)
         }
 #undef RROI_GATHER
     }

@@ -430,7 +430,7 @@ struct RoiSource {   // NCHW_SRC: where the storer takes its affines from
     float spatial_scale;
     int trig;
 };
-template <bool VEC_STORE, int EARLY, int OCC, int HID, bool ONHWC, int SHIFT, bool NCHW_SRC = false>
+template <bool VEC_STORE, int EARLY, int OCC, int HID, bool ONHWC, int SHIFT, bool NCHW_SRC = false, int WAUX = -1>
 __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     const float* __restrict__ map, const Affine* __restrict__ aff, float* __restrict__ out,
     int num_rois, int C, int height, int width, int pooled_width, int NB, int batch_size,
@@ -715,7 +715,19 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             const unsigned off = (r * (unsigned)NB + bin0) * 4u;
             const v4f o = {a0 ? v[s4].x : 0.f, a1 ? v[s4].y : 0.f, a2 ? v[s4].z : 0.f, a3 ? v[s4].w : 0.f};
             if (VEC_STORE) {  // NB % 4 == 0: the 4 bins are all inside or all outside the row
-                if (s4 < kMinorStores)
+                // WAUX >= 0: ONE policy for all eight stores (the merging form for rows that are not whole sectors, see the host)
+                if (WAUX >= 0) {
+                    // any NB: a quad wholly inside the row is ONE 16-byte store (dword-aligned: the rows of such crops start
+                    // anywhere); the row's last quad, when NB % 4 != 0, leaves as its <= 3 valid dwords -- in a row's last tile only
+                    constexpr int A = WAUX >= 0 ? WAUX : 0;
+                    buf_store<A>(ws, (live && bin0 + 4u <= (unsigned)NB) ? off : kOOB, o);
+                    if (t == (unsigned)ntiles - 1u && ((unsigned)NB & 3u)) {   // (wave-uniform)
+                        const bool part = live && bin0 < (unsigned)NB && bin0 + 4u > (unsigned)NB;
+                        buf_store1<A>(ws, part ? off + 0 : kOOB, o.x);
+                        buf_store1<A>(ws, (part && bin0 + 1 < (unsigned)NB) ? off + 4 : kOOB, o.y);
+                        buf_store1<A>(ws, (part && bin0 + 2 < (unsigned)NB) ? off + 8 : kOOB, o.z);
+                    }
+                } else if (s4 < kMinorStores)
                     buf_store<kMinorAux>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);
                 else
                     buf_store<kStoreAux>(ws, (live && bin0 < (unsigned)NB) ? off : kOOB, o);

@@ -64,14 +64,18 @@ def test_forward_bit_exact(ext, oracle, name, path):
     assert n == 0 and d <= FWD_TOL, f"{n} elements differ, max |d| = {d}"
 
 
-@pytest.mark.parametrize("case", ["train_c64_b2", "c32_b3", "c40_b2_cl", "many_rois", "one_image_band", "more_images_than_buckets"])
+@pytest.mark.parametrize("case", ["train_c64_b2", "c32_b3", "c40_b2_cl", "many_rois", "one_image_band", "more_images_than_buckets",
+                                  "merge_11x83", "merge_11x82", "merge_11x85", "merge_c32_11x84"])
 def test_forward_xcd_groups(ext, oracle, case):
     """Round 5: C <= 64 (one or two channel chunks) and >= 64 ROIs take the XCD-GROUP form of the tiled forward -- the
     ROIs are counting-sorted by (image, centre row) inside the prologue launch and each group of XCDs gathers one
     quantile of them.  The order only ever decides WHO computes a crop: every case is bit-exact against the oracle,
     including ROIs whose image index is invalid, centres at NaN and infinity (they sort to an end), more than
     1024 ROIs (the sort's ranks beyond its registers go through memory), more images than the sort has buckets,
-    channels-last features consumed in place and channels-last crops."""
+    channels-last features consumed in place and channels-last crops.
+    The merge_* cases are large enough (>= 64 MB of crops over a small map) for the MERGING form on rows that are not whole
+    64-byte sectors: strided tiles whose partial sectors meet in the group's L2, 16-byte stores at dword alignment and a
+    row's last one to three dwords stored singly (913, 902 and 935 bins a row: 1, 2 and 3 of them; 924: none)."""
     rng = np.random.default_rng(4242)
     cl = False
     if case == "train_c64_b2":
@@ -84,6 +88,10 @@ def test_forward_xcd_groups(ext, oracle, case):
         B, C, H, W, R, ph, pw = 2, 8, 40, 60, 1500, 4, 16
     elif case == "one_image_band":
         B, C, H, W, R, ph, pw = 4, 64, 48, 64, 128, 11, 32
+    elif case.startswith("merge_c32"):
+        B, C, H, W, R, ph, pw = 2, 32, 60, 80, 600, 11, 84
+    elif case.startswith("merge_"):
+        B, C, H, W, R, ph, pw = 2, 64, 60, 80, 300, 11, int(case[-2:])
     else:
         B, C, H, W, R, ph, pw = 1100, 4, 8, 8, 2300, 2, 8
     f = rng.standard_normal((B, C, H, W), dtype=np.float32)

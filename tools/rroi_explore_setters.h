@@ -104,3 +104,4 @@ int rroi_align_debug_set_fwd_patch(int on, int waves, int cwave)
     return old;
 }
 int rroi_align_debug_set_bwd_pair_aggregate(int v) { const int old = g_tune.bwd_pair_aggregate; g_tune.bwd_pair_aggregate = v; return old; }
+int rroi_align_debug_set_fwd_merge(int v) { const int old = g_tune.fwd_merge; g_tune.fwd_merge = v; return old; }
