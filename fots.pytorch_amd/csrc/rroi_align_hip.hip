@@ -255,7 +255,7 @@ struct Workspace {
 
 // XCD groups (XcdGroups, rroi_forward_kernels.h): G = 8 / nchunks groups per chunk for one or two chunks (C <= 64)
 // and enough ROIs; else one group, the mapping of rounds 1-4
-int forward_groups(int num_rois, int nchunks, size_t out_bytes)
+int forward_groups(int num_rois, int nchunks, size_t out_bytes, bool whole_sector_rows)
 {
     // measured (tools/groups_ab.py, profiles/r05_groups_ab.txt; us per call, one group / G groups): C = 64, two
     // 120 x 160 maps, 11 x 96: R = 512 38.3 / 33.3, R = 128 19.0 / 15.2, R = 32 12.0 / 12.4 (the sort's block is the last of
@@ -263,9 +263,13 @@ int forward_groups(int num_rois, int nchunks, size_t out_bytes)
     // the same with the cheap sort (r05_groups_ab2.txt): R = 512 38.2 / 32.1 (11 x 83: 39.3 / 32.9, 11 x 100: 42.0 / 35.3), R = 64
     // 14.3 / 12.7, R = 32 12.0 / 12.1; eight 160 x 160 maps, R = 512, 11 x 100: 57.3 / 47.3.  ROIs bunched in a third of
     // one image: +0.5 us.  Crops beyond the 256 MB memory-side cache (R = 2048, 11 x 100, 577 MB): 260 / 289 -- the
-    // sorted order scatters the stores of a moment over the whole tensor: one group there.
+    // sorted order scatters the stores of a moment over the whole tensor: one group there.  That is the half-line windows'
+    // matter only (store stream alone beyond the cache: 3.1 TB/s, tools/big_crops_ablate.py): crops of WHOLE-SECTOR rows
+    // gain more there than anywhere (tools/big_crops_probe.py, profiles/r05_big_crops.txt: eight 160 x 160 maps, R = 2048,
+    // 11 x 96, 528 MB: 152.7 / 117.9; two 120 x 160 maps: 103.5 / 98.9 for the gather) -- a (roi, chunk) block's 135 KB
+    // leave one XCD together.
     if (!g_tune.fwd_groups || (nchunks != 1 && nchunks != 2)) return 1;
-    if (out_bytes > ((size_t)256 << 20)) return 1;
+    if (out_bytes > ((size_t)256 << 20) && !whole_sector_rows && g_tune.fwd_groups < 2) return 1;   // (2: tools only)
     const int G = 8 / nchunks;
     return num_rois >= g_tune.fwd_groups_min_rois ? G : 1;
 }
@@ -763,7 +767,8 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     const bool zero_copy = feature_layout == RROI_LAYOUT_NHWC;
     const float* map = zero_copy ? features : ws.cm;
     const int pitch = row_pitch(width);
-    const int groups = launcher_rest ? 1 : forward_groups(num_rois, nchunks, (size_t)num_rois * channels * NB * sizeof(float));
+    const int groups = launcher_rest ? 1 : forward_groups(num_rois, nchunks, (size_t)num_rois * channels * NB * sizeof(float),
+                                                             NB % 16 == 0 && !out_nhwc);
 
     // prologue: relayout + affine table in one launch
     if (stages & RROI_STAGE_PROLOGUE) {

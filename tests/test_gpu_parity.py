@@ -128,6 +128,26 @@ def test_forward_xcd_groups(ext, oracle, case):
     assert eq(out.cpu().numpy(), want)
 
 
+def test_forward_xcd_groups_beyond_the_cache(ext, oracle):
+    """Crops of whole-sector rows keep their XCD groups beyond the 256 MB memory-side cache (297 MB here; rows that are
+    not whole sectors go back to one group there): the tiled path against the direct kernel on all of it, and against
+    the oracle on a sample of the ROIs."""
+    rng = np.random.default_rng(99)
+    B, C, H, W, R, ph, pw = 2, 64, 60, 80, 1100, 11, 96
+    f = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    h = rng.uniform(8, 40, R)
+    r = np.stack([rng.integers(0, B, R), rng.uniform(-10, 4 * W + 10, R), rng.uniform(-10, 4 * H + 10, R), h,
+                  h * rng.uniform(1, 9, R), rng.uniform(-90, 90, R)], 1).astype(np.float32)
+    Fd, Rd = dev(f), dev(r)
+    got = ext.forward(Fd, Rd, ph, pw, 0.25, path=ext.PATH_TILED)
+    assert got.numel() * 4 > 256 << 20
+    direct = ext.forward(Fd, Rd, ph, pw, 0.25, path=ext.PATH_DIRECT)
+    assert torch.equal(got.view(torch.int32), direct.view(torch.int32))
+    pick = np.sort(rng.choice(R, 48, replace=False))
+    want = oracle.forward_c(f, r[pick], ph, pw, 0.25, threads=8)
+    assert eq(got[torch.from_numpy(pick).cuda()].cpu().numpy(), want)
+
+
 def test_forward_tiny_maps_every_path(ext, oracle):
     """Maps of one to five pixels a side (the direct path's row PAIRS -- 8-byte loads that start at x0, or at x0 - 1 on a
     row's last pixel -- have nowhere to go wrong but here; a map one pixel wide takes the thread-per-bin fallback), odd
