@@ -89,9 +89,10 @@ def test_forward_xcd_groups(ext, oracle, case):
     elif case == "one_image_band":
         B, C, H, W, R, ph, pw = 4, 64, 48, 64, 128, 11, 32
     elif case.startswith("merge_c32"):
-        B, C, H, W, R, ph, pw = 2, 32, 60, 80, 600, 11, 84
+        B, C, H, W, R, ph, pw, cl = 2, 32, 60, 80, 600, 11, 84, True   # (+ the merging form over channels-last features in place)
     elif case.startswith("merge_"):
         B, C, H, W, R, ph, pw = 2, 64, 60, 80, 300, 11, int(case[-2:])
+        cl = pw == 85
     else:
         B, C, H, W, R, ph, pw = 1100, 4, 8, 8, 2300, 2, 8
     f = rng.standard_normal((B, C, H, W), dtype=np.float32)
