@@ -99,6 +99,8 @@ struct Tuning {
     double fwd_fused_min_elems = 1.5e6;   // ... from this many output elements up (below: the direct kernel) ...
     int fwd_fused_min_channels = 128;     // ... and this many channels
     double fwd_tiled_min_elems = 3.8e6;   // ... and the two-launch path from this many up
+    int fwd_shift_lines = 1;      // 1: line-aligned windows for rows that are not whole sectors beyond 320 MB of crops (round 5); 0: never; 2: always
+    int shift_lines_wgs_per_cu = 10;
     int fwd_merge = 1;            // rows that are not whole sectors under XCD groups: strided tiles + plain stores where it pays (round 5); 0: SHIFT always; 2: always
     int fwd_groups = 1;           // XCD groups for nchunks in {1, 2} (round 5; XcdGroups in rroi_forward_kernels.h); 0: off
     int fwd_groups_min_rois = 64; // ... from this many ROIs up
@@ -255,21 +257,21 @@ struct Workspace {
 
 // XCD groups (XcdGroups, rroi_forward_kernels.h): G = 8 / nchunks groups per chunk for one or two chunks (C <= 64)
 // and enough ROIs; else one group, the mapping of rounds 1-4
-int forward_groups(int num_rois, int nchunks, size_t out_bytes, bool whole_sector_rows)
+int forward_groups(int num_rois, int nchunks)
 {
     // measured (tools/groups_ab.py, profiles/r05_groups_ab.txt; us per call, one group / G groups): C = 64, two
     // 120 x 160 maps, 11 x 96: R = 512 38.3 / 33.3, R = 128 19.0 / 15.2, R = 32 12.0 / 12.4 (the sort's block is the last of
     // its launch to finish: few ROIs keep one group); C = 128 (G = 2, a 3.3 MB slice per XCD already): 33.4 / 33.5
     // the same with the cheap sort (r05_groups_ab2.txt): R = 512 38.2 / 32.1 (11 x 83: 39.3 / 32.9, 11 x 100: 42.0 / 35.3), R = 64
     // 14.3 / 12.7, R = 32 12.0 / 12.1; eight 160 x 160 maps, R = 512, 11 x 100: 57.3 / 47.3.  ROIs bunched in a third of
-    // one image: +0.5 us.  Crops beyond the 256 MB memory-side cache (R = 2048, 11 x 100, 577 MB): 260 / 289 -- the
-    // sorted order scatters the stores of a moment over the whole tensor: one group there.  That is the half-line windows'
-    // matter only (store stream alone beyond the cache: 3.1 TB/s, tools/big_crops_ablate.py): crops of WHOLE-SECTOR rows
-    // gain more there than anywhere (tools/big_crops_probe.py, profiles/r05_big_crops.txt: eight 160 x 160 maps, R = 2048,
-    // 11 x 96, 528 MB: 152.7 / 117.9; two 120 x 160 maps: 103.5 / 98.9 for the gather) -- a (roi, chunk) block's 135 KB
-    // leave one XCD together.
+    // one image: +0.5 us.  Crops beyond the 256 MB memory-side cache: with the HALF-line windows of the SHIFT form the sorted
+    // order scattered a moment's half lines over the whole tensor (R = 2048, 11 x 100, 577 MB: 260 / 289) and the first
+    // version kept one group there; stores of whole lines gain more beyond the cache than anywhere (tools/big_crops_probe.py,
+    // profiles/r05_big_crops.txt: rows of whole sectors, eight 160 x 160 maps, R = 2048, 11 x 96, 528 MB: 152.7 / 117.9; the
+    // line-aligned windows that such sizes now take, 11 x 100: 192-208 / 167, 11 x 83: 173-185 / 145-151) -- a (roi, chunk)
+    // block's 135 KB leave one XCD together -- and between 256 and 320 MB the groups bring the merging form with them
+    // (tools/shift_lines_threshold.py: 267 MB 80-86 / 66-67, 275 MB 73-85 / 73-75, eight maps 118-123 / 112): no size limit.
     if (!g_tune.fwd_groups || (nchunks != 1 && nchunks != 2)) return 1;
-    if (out_bytes > ((size_t)256 << 20) && !whole_sector_rows && g_tune.fwd_groups < 2) return 1;   // (2: tools only)
     const int G = 8 / nchunks;
     return num_rois >= g_tune.fwd_groups_min_rois ? G : 1;
 }
@@ -432,6 +434,7 @@ enum class FwdKernel {
     kChannelsLast,   // channels-last crops (R, PH, PW, C)
     kShift,          // SHIFT: overlapped tiles, sector-aligned store windows -- crops whose rows are not whole sectors
     kStridedMerge,   // strided tiles on rows that are not whole sectors, plain stores: the XCD's L2 merges the partial sectors (XCD groups only)
+    kShiftLines,     // SHIFT == 2: line-aligned windows (32 own bins of 64 gathered) -- such crops beyond the memory-side cache
 };
 struct ForwardPlan {
     FwdKernel kernel;
@@ -455,6 +458,18 @@ ForwardPlan plan_forward_gather(int num_rois, int channels, int NB, int nchunks,
     // like the strided form's.  It costs 4 / 3 of the gather work per byte and was never slower than the strided items on
     // such crops, from R = 8 to R = 2048 (tools/align_probe.py, profiles/r04_align_probe.txt: R = 32, C = 64, 11 x 83: 6.6
     // against 9.4 us; R = 128, 11 x 100: 13.7 against 16.5; R = 512, 11 x 83: 40 against 209)
+    // Round 5: beyond the 256 MB memory-side cache a half line reaches HBM as a half line -- the SHIFT
+    // form's store stream ALONE runs at 3.1 TB/s there (tools/big_crops_ablate.py).  SHIFT == 2 stores whole LINES: a tile
+    // advances by 32 bins and gathers 64 (twice the gather work per byte instead of 4 / 3).  tools/shift_lines_ab.py,
+    // profiles/r05_shift_lines.txt (us per call, SHIFT / lines): eight 160 x 160 maps, C = 64, R = 2048, 11 x 100 (550 MB) 255 / 191;
+    // two 120 x 160 maps, 11 x 83: R = 2048 (456 MB) 172 / 141, R = 4096 (913 MB) 358 / 272; C = 256, 11 x 50, R = 1024 (550 MB)
+    // 251 / 176; 11 x 100, R = 600 (645 MB) 215 / 183.  Around the cache's size it is a draw or worse (267-275 MB: 80 / 87,
+    // 73 / 87, 104 / 93, 76 / 83; 322-334 MB: 105 / 97, 112 / 108): from 320 MB up.
+    if (NB % 16 != 0 && (g_tune.fwd_shift_lines == 2 ||
+                         (g_tune.fwd_shift_lines == 1 && (size_t)num_rois * channels * NB * sizeof(float) > ((size_t)320 << 20)))) {
+        const int nt = ceil_div(NB, kTileBins - 32);
+        return {FwdKernel::kShiftLines, tiled_grid((long)num_rois * nt, nchunks, g_tune.shift_lines_wgs_per_cu), nt, base_dbg};
+    }
     // Round 5, with XCD groups: ALL tiles of a (roi, chunk) block go through ONE XCD at about the same time, so the partial
     // sectors that strided tiles leave at their ends on rows that are not whole sectors meet in that XCD's L2 -- if the
     // stores are plain (write-back) instead of streamed.  Then such crops need no SHIFT form (4 / 3 of the items): strided
@@ -767,8 +782,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     const bool zero_copy = feature_layout == RROI_LAYOUT_NHWC;
     const float* map = zero_copy ? features : ws.cm;
     const int pitch = row_pitch(width);
-    const int groups = launcher_rest ? 1 : forward_groups(num_rois, nchunks, (size_t)num_rois * channels * NB * sizeof(float),
-                                                             NB % 16 == 0 && !out_nhwc);
+    const int groups = launcher_rest ? 1 : forward_groups(num_rois, nchunks);
 
     // prologue: relayout + affine table in one launch
     if (stages & RROI_STAGE_PROLOGUE) {
@@ -828,6 +842,7 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
         case FwdKernel::kChannelsLast:  RROI_GATHER(true, 2, 5, 2, true, 0); break;    // 91 VGPRs: 10 per CU
         case FwdKernel::kShift:         RROI_GATHER(true, 0, 6, 3, false, 1); break;    // 79 VGPRs, 12.4 KB of LDS: 12 per CU
         case FwdKernel::kStridedMerge:  RROI_GATHER(true, 0, 6, 3, false, 0, false, 0); break;   // plain stores (write-through: 32.1 against 30.1 us)
+        case FwdKernel::kShiftLines:    RROI_GATHER(true, 0, 5, 3, false, 2); break;    // 84 VGPRs, 14.8 KB of LDS: 10 per CU
         }
 #undef RROI_GATHER
     }

@@ -414,6 +414,10 @@ constexpr int kMinorStores = 1;   // ... except this many of a tile's eight, whi
 #define RROI_SHIFT_AUX 16
 #endif
 constexpr int kShiftAux = RROI_SHIFT_AUX;
+#ifndef RROI_SHIFT2_AUX
+#define RROI_SHIFT2_AUX 2
+#endif
+constexpr int kShift2Aux = RROI_SHIFT2_AUX;   // the line-aligned windows (SHIFT == 2) stream: whole lines (tools/kbench bigout: nt 4.3-5.0 TB/s, sc1 4.0-4.8)
 // Workgroup barrier that orders LDS traffic only: s_barrier does not wait for vector memory, and unlike
 // __syncthreads() nothing here makes the compiler emit s_waitcnt vmcnt(0).
 __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -464,9 +468,13 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // tile's own (the first 16 are the tile before's last: every item is self-contained, see drain_shift); row 64 takes
     // the padding records, rows 65..79 are never written (a window position beyond the gathered bins reads them and
     // is never stored).  10240 B; with the records 12720 B = 10 granules, like the channel-major tile
-    constexpr unsigned kBmRows = kTileBins + 16;
-    constexpr int kOwnBins = SHIFT ? kTileBins - 16 : kTileBins;   // bins a tile stores / advances by
-    static_assert(SHIFT == 0 || SHIFT == 1, "SHIFT is a flag");
+    // SHIFT == 2 (round 5, crops beyond the memory-side cache): LINE-aligned windows instead -- a tile advances by 32 bins and
+    // gathers 64 (its own 32 and the 32 in front: all a window shifted by h <= 31 can reach), every store instruction is
+    // eight rows x one whole 128-byte line (see drain_shift2); rows up to 95 can be read (and are never stored): 12288 B
+    constexpr int kFront = SHIFT == 2 ? 32 : SHIFT ? 16 : 0;       // gathered bins in front of a tile's own
+    constexpr unsigned kBmRows = kTileBins + kFront;
+    constexpr int kOwnBins = kTileBins - kFront;                   // bins a tile stores / advances by
+    static_assert(SHIFT >= 0 && SHIFT <= 2, "SHIFT: 0 none, 1 sector-aligned windows, 2 line-aligned windows");
     __shared__ __attribute__((aligned(16))) float T[SHIFT ? kBmRows * kChunk : kChunk * kTStride + 3 * kTStride + 32];
     // tap records of two items: item i+1 is sampled out of one set while the other is being
     // built for item i+2
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         auto tile_pos = [](unsigned lane_of_bin) -> unsigned { return lane_of_bin; };
         const bool batch_ok = A.batch >= 0 && A.batch < batch_size;
         // SHIFT: lanes 0..15 are the 16 bins in front of the tile's own 48 (negative for the first tile of a row)
-        const int sbin = (int)(t * (unsigned)kOwnBins + lane) - (SHIFT ? 16 : 0);
+        const int sbin = (int)(t * (unsigned)kOwnBins + lane) - kFront;
         const unsigned bin = (unsigned)max(sbin, 0);
         const unsigned ph = fdiv(bin, div_pw);
         const unsigned pw = bin - ph * (unsigned)pooled_width;
@@ -847,6 +855,82 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
         }
     };
 
+    // SHIFT == 2: the same idea with LINE-aligned windows, for crops larger than the 256 MB memory-side cache -- there a half
+    // line reaches HBM as a half line, and the store stream of the 48-bin windows alone runs at 3.1 TB/s (profiles/
+    // r05_big_crops.txt; whole lines: 4.0-5.0 in tools/kbench bigout).  h = (row's float offset in memory) mod 32; window
+    // position p of tile t is bin 32 t + p - h of the row; a tile stores ONE line per row (two in a row's last tile, whose
+    // window runs on to the row's end) and gathers 64 bins for it: 2 x the gather work per byte (SHIFT == 1: 4 / 3).
+    // lane = (row of eight, 16-byte piece of the line): the eight lanes of a line are neighbours (what the TCP coalesces),
+    // instruction i = (u = i & 3: row row8 + 8 u, s = i >> 2: line of the window).  Rows 8 apart do not share h when NB is
+    // odd, so every instruction has its own h and its own LDS address (16 ds_read_b32 per line set).
+    auto drain_shift2 = [&](unsigned n, unsigned t, unsigned long long cur_mask, bool skip) {
+        const unsigned row8 = lane >> 3, pc = lane & 7u;
+        const unsigned nb31 = (unsigned)NB & 31u;
+        const unsigned h0 = (((unsigned)(reinterpret_cast<size_t>(out) >> 2) & 31u) +
+                             (((n & 31u) * ((unsigned)C & 31u)) & 31u) * nb31) & 31u;   // (k * 32 channels: whole lines)
+        const int left = NB - (int)(t * (unsigned)kOwnBins);
+        const bool first = t == 0, last = left <= kOwnBins;
+        v4f o[8];
+        unsigned hh[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hh[u] = (h0 + (row8 + 8u * u) * nb31) & 31u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if ((i >> 2) == 1 && !last) continue;   // the second line exists in a row's last tile only
+            const unsigned u = i & 3, r = row8 + 8u * u;
+            const float* wp = T + ((unsigned)kFront + 32u * (i >> 2) + 4u * pc - hh[u]) * kChunk + r;
+            o[i] = v4f{wp[0], wp[kChunk], wp[2 * kChunk], wp[3 * kChunk]};
+        }
+        // the <= 3 floats in front of / behind the whole 16-byte pieces of a row's valid positions (first / last tile)
+        float fix[4] = {0.f, 0.f, 0.f, 0.f};
+        const unsigned fr = lane & 31u, fi = lane >> 5;
+        const unsigned fh = (h0 + fr * nb31) & 31u;
+        const int pl = first ? (int)fh : 0;
+        const int ph = last ? left + (int)fh : kOwnBins;   // (<= 63)
+        auto win_at = [&](unsigned rr, int pos, unsigned hrow) -> float {
+            const unsigned ln = (unsigned)(pos - (int)hrow + kFront);   // the lane that gathered it (< 64 where valid)
+            const float x = T[ln * kChunk + rr];
+            return ((cur_mask >> (ln & 63u)) & 1ull) ? x : 0.0f;
+        };
+        if (first || last) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int pa = pl + (int)fi + 2 * ps, pb = (ph & ~3) + (int)fi + 2 * ps;
+                if (pa < ((pl + 3) & ~3) && pa < ph) fix[ps] = win_at(fr, pa, fh);
+                if (pb < ph && pb >= pl && (ph & ~3) >= ((pl + 3) & ~3)) fix[2 + ps] = win_at(fr, pb, fh);
+            }
+        }
+        wg_lds_barrier();  // T has been read: the gatherer may blend the next tile into it
+        const bool live = !(dbg & 1) && !skip;
+        float* obase = out + ((size_t)n * C + k * kChunk) * NB;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(obase, chans_here * (unsigned)NB * 4u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if ((i >> 2) == 1 && !last) continue;
+            const unsigned u = i & 3, r = row8 + 8u * u, h = hh[u];
+            const int p0 = 32 * (i >> 2) + 4 * (int)pc;
+            const int rl = first ? (int)h : 0, rh = last ? left + (int)h : kOwnBins;
+            // the lanes that gathered the piece: kFront + p0 - h .. + 3 (< 64 where the piece is whole)
+            const unsigned msh = (unsigned)kFront + 4u * pc - h;   // <= 60
+            const unsigned nib = (unsigned)((cur_mask >> (32 * (i >> 2))) >> msh);
+            const v4f v = {(nib & 1u) ? o[i].x : 0.f, (nib & 2u) ? o[i].y : 0.f, (nib & 4u) ? o[i].z : 0.f,
+                           (nib & 8u) ? o[i].w : 0.f};
+            const bool whole = p0 >= rl && p0 + 4 <= rh;
+            const unsigned off = (r * (unsigned)NB + t * (unsigned)kOwnBins + (unsigned)p0 - h) * 4u;
+            buf_store<kShift2Aux>(ws, (live && whole && r < chans_here) ? off : kOOB, v);
+        }
+        if (first || last) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int pa = pl + (int)fi + 2 * ps, pb = (ph & ~3) + (int)fi + 2 * ps;
+                const bool oka = live && fr < chans_here && pa < ((pl + 3) & ~3) && pa < ph;
+                const bool okb = live && fr < chans_here && pb < ph && pb >= pl && (ph & ~3) >= ((pl + 3) & ~3);
+                buf_store1<kShift2Aux>(ws, oka ? (fr * (unsigned)NB + t * (unsigned)kOwnBins + (unsigned)pa - fh) * 4u : kOOB, fix[ps]);
+                buf_store1<kShift2Aux>(ws, okb ? (fr * (unsigned)NB + t * (unsigned)kOwnBins + (unsigned)pb - fh) * 4u : kOOB, fix[2 + ps]);
+            }
+        }
+    };
+
     // The two waves walk the same items.  gfx950 counts loads and stores with ONE in-order counter, so in
     // a wave that does both a load issued after a tile's stores cannot be consumed before those stores are
     // acknowledged (microseconds, with 256 MiB streaming out).  Here no wave does both: the gatherer's vmcnt only ever sees loads, the storer's only
@@ -886,7 +970,8 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
             wg_lds_barrier();  // 1: records of item `cur` are in set p; the tile of the previous item is in T
             if (have_prev) {
                 // T -> registers | barrier 2 | stores
-                if (SHIFT) drain_shift(n_prev, t_prev, mask_prev, skip_prev);
+                if (SHIFT == 2) drain_shift2(n_prev, t_prev, mask_prev, skip_prev);
+                else if (SHIFT) drain_shift(n_prev, t_prev, mask_prev, skip_prev);
                 else drain_tile(n_prev, t_prev, mask_prev, skip_prev);
             } else {
                 wg_lds_barrier();

@@ -129,19 +129,24 @@ def test_forward_xcd_groups(ext, oracle, case):
     assert eq(out.cpu().numpy(), want)
 
 
-def test_forward_xcd_groups_beyond_the_cache(ext, oracle):
-    """Crops of whole-sector rows keep their XCD groups beyond the 256 MB memory-side cache (297 MB here; rows that are
-    not whole sectors go back to one group there): the tiled path against the direct kernel on all of it, and against
-    the oracle on a sample of the ROIs."""
+@pytest.mark.parametrize("pw", [96, 83, 50])
+def test_forward_beyond_the_cache(ext, oracle, pw):
+    """Crops beyond the 256 MB memory-side cache.  Rows of whole sectors (11 x 96, 297 MB) keep their XCD groups there;
+    rows that are not (11 x 83: 330 MB at C = 64; 11 x 50 at C = 136 -- a last chunk of eight channels --: 335 MB) go back
+    to one group and, from 320 MB up, take the LINE-aligned form (SHIFT == 2: a tile stores 32 bins of the 64 it gathers,
+    every store a whole 128-byte line).  The tiled path against the direct kernel on all of it, and against the oracle
+    on a sample of the ROIs."""
     rng = np.random.default_rng(99)
-    B, C, H, W, R, ph, pw = 2, 64, 60, 80, 1100, 11, 96
+    B, C, H, W, R, ph = 2, 64, 60, 80, 1100 if pw == 96 else 1480, 11
+    if pw == 50:
+        C, R = 136, 1170
     f = rng.standard_normal((B, C, H, W), dtype=np.float32)
     h = rng.uniform(8, 40, R)
     r = np.stack([rng.integers(0, B, R), rng.uniform(-10, 4 * W + 10, R), rng.uniform(-10, 4 * H + 10, R), h,
                   h * rng.uniform(1, 9, R), rng.uniform(-90, 90, R)], 1).astype(np.float32)
     Fd, Rd = dev(f), dev(r)
     got = ext.forward(Fd, Rd, ph, pw, 0.25, path=ext.PATH_TILED)
-    assert got.numel() * 4 > 256 << 20
+    assert got.numel() * 4 > (256 << 20 if pw == 96 else 320 << 20)
     direct = ext.forward(Fd, Rd, ph, pw, 0.25, path=ext.PATH_DIRECT)
     assert torch.equal(got.view(torch.int32), direct.view(torch.int32))
     pick = np.sort(rng.choice(R, 48, replace=False))

@@ -105,3 +105,4 @@ int rroi_align_debug_set_fwd_patch(int on, int waves, int cwave)
 }
 int rroi_align_debug_set_bwd_pair_aggregate(int v) { const int old = g_tune.bwd_pair_aggregate; g_tune.bwd_pair_aggregate = v; return old; }
 int rroi_align_debug_set_fwd_merge(int v) { const int old = g_tune.fwd_merge; g_tune.fwd_merge = v; return old; }
+int rroi_align_debug_set_fwd_shift_lines(int v, int wgs_per_cu) { const int old = g_tune.fwd_shift_lines; g_tune.fwd_shift_lines = v; if (wgs_per_cu > 0) g_tune.shift_lines_wgs_per_cu = wgs_per_cu; return old; }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The split kernel's SHIFT forms (runs of tiles, sector-aligned store windows) against its strided form, forced
+"""The split kernel's SHIFT forms (sector-aligned store windows; round 5: + the LINE-aligned windows, SHIFT == 2) against its strided form, forced
 through the explore build (tools/build_explore.sh) on random shapes: pooled sizes of every residue mod 16, channel
 counts that are not multiples of 32, several images, degenerate and non-finite ROIs, crops that start 4 / 8 / 12
 bytes off a 16-byte boundary, every cut of the blocks into runs.  Bit for bit, the NaN payloads included.
@@ -45,22 +45,28 @@ for tr in range(trials):
         f[0, 0, int(rng.integers(0, H)), int(rng.integers(0, W))] = np.nan
     F, Rt = torch.from_numpy(f).cuda(), torch.from_numpy(r).cuda()
     n_out = R * C * ph * pw
-    skew = int(rng.integers(0, 4))   # crops that start 0 / 4 / 8 / 12 bytes off a 16-byte boundary
-    bufs = [torch.full((n_out + 8,), float("nan"), device="cuda") for _ in range(2)]
+    skew = int(rng.integers(0, 4)) if rng.random() < 0.5 else int(rng.integers(0, 32))   # crops that start anywhere in a 128-byte line
+    bufs = [torch.full((n_out + 40,), float("nan"), device="cuda") for _ in range(3)]
     outs = [b[skew:skew + n_out] for b in bufs]
     nb = lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, 0)
     ws = torch.empty(max(nb, 1), dtype=torch.uint8, device="cuda")
     parts = int(rng.integers(0, 6))
     wgs = int(rng.choice([0, 0, 2, 4]))
-    for mode, o in ((0, outs[0]), (2, outs[1])):
+    for mode, lines, o in ((0, 0, outs[0]), (2, 0, outs[1]), (0, 2, outs[2])):
         lib.rroi_align_debug_set_fwd_shift(mode, wgs, parts)
+        lib.rroi_align_debug_set_fwd_shift_lines(lines, 0)
         rc = lib.rroi_align_forward_hip(F.data_ptr(), 0, s, B, R, H, W, C, ph, pw, Rt.data_ptr(), o.data_ptr(), ws.data_ptr(), nb, 2, st)
         assert rc == 1, rc
     torch.cuda.synchronize()
-    a, b = (x.cpu().numpy().view(np.uint32) for x in bufs)
+    a, b, c = (x.cpu().numpy().view(np.uint32) for x in bufs)
+    if not np.array_equal(a, c):
+        bad += 1
+        d = np.nonzero(a != c)[0]
+        print(f"trial {tr} LINES: C={C} {H}x{W} B={B} {ph}x{pw} R={R} skew={skew}: {d.size} words differ, first at {d[:5]}")
     if not np.array_equal(a, b):   # the guard floats around the crops included
         bad += 1
         d = np.nonzero(a != b)[0]
         print(f"trial {tr}: C={C} {H}x{W} B={B} {ph}x{pw} R={R} skew={skew} parts={parts} wgs={wgs}: {d.size} words differ, first at {d[:5]}")
 lib.rroi_align_debug_set_fwd_shift(1, 0, 0)
+lib.rroi_align_debug_set_fwd_shift_lines(1, 0)
 print(f"shift fuzz: {trials} trials, {bad} mismatches")
