@@ -397,8 +397,8 @@ __global__ void rroi_affine_kernel(const float* __restrict__ rois, int num_rois,
 // here no wave does both.
 // Template parameters: VEC_STORE 16-byte stores (PH * PW % 4 == 0) | EARLY LO groups issued before barrier 2 | OCC
 // waves per SIMD (__launch_bounds__) | HID HI groups double-buffered unrolled (2) or rolled (3) | ONHWC channels-last
-// crops | SHIFT crops whose rows are not whole 64-byte sectors: overlapped tiles and sector-aligned store windows,
-// any row offset (see drain_shift) | NCHW_SRC the one-launch form over the caller's NCHW map (below) | WAUX >= 0 the MERGING form for
+// crops | SHIFT crops whose rows are not whole 64-byte sectors: overlapped tiles and sector-aligned (1) or, for crops beyond
+// the memory-side cache, line-aligned (2) store windows, any row offset (see drain_shift, drain_shift2) | NCHW_SRC the one-launch form over the caller's NCHW map (below) | WAUX >= 0 the MERGING form for
 // such crops under XCD groups: strided tiles, every store with that one cache policy (0 = plain write-back: the XCD's L2 puts a
 // row's partial sectors together), 16-byte stores at dword alignment.  dbg: bit 0 drops the stores, bit 1
 // the tap loads (ablations), bit 5 the reference-ABI launcher's mode.  (The per-workgroup time stamps, the
