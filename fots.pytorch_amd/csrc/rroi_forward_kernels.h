@@ -463,7 +463,8 @@ __global__ __launch_bounds__(2 * kWave, OCC) void rroi_fwd_split_kernel(
     // tile's pitch, 32 columns: 32 different banks).  LDS is granted in 1280-byte granules on gfx950;
     // the block (T 9648 + records 2448 = 12096 B) stays within the 10 granules that 12 waves per CU
     // allow (a smaller block that admits 14 was measured in round 2 and is no faster: the kernel is bound by the
-    // write path, not by latency; profiles/NOTEBOOK.md 5.2).
+    // write path, not by latency; profiles/NOTEBOOK.md 5.2 -- and again in round 5 at the 64-channel shapes, without the
+    // pad area, 11,192 B, seven waves per SIMD: R = 512, 11 x 96 33.2 against 32.6-32.9 us, 11 x 83 32.0 against 30.2-31.0).
     // SHIFT: the tile is BIN-MAJOR instead -- T[lane's bin * 32 + channel], 64 gathered bins of which the LAST 48 are the
     // tile's own (the first 16 are the tile before's last: every item is self-contained, see drain_shift); row 64 takes
     // the padding records, rows 65..79 are never written (a window position beyond the gathered bins reads them and
