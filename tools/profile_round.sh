@@ -8,7 +8,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/round
 rm -rf $OUT; mkdir -p $OUT
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
-RROI_BENCH_TRAFFIC=0 RROI_BENCH_E2E=0 RROI_BENCH_SENSITIVITY=0 RROI_BENCH_TRAIN=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- \
+RROI_BENCH_TRAFFIC=0 RROI_BENCH_E2E=0 RROI_BENCH_SENSITIVITY=0 RROI_BENCH_TRAIN=0 RROI_BENCH_BIG=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- \
     python bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 # the driver's flags (K = 20 after W = 5), for the record
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_driver_flags.json 2>> $OUT/bench.err
