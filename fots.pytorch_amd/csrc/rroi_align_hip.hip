@@ -446,8 +446,11 @@ struct ForwardPlan {
 constexpr int kShiftWgsPerCu = 12;   // the SHIFT instantiation: <= 80 VGPRs under __launch_bounds__(128, 6), 12.4 KB of LDS
 constexpr int kShiftOwnBins = kTileBins - 16;   // bins a SHIFT tile advances by (it gathers 64: kOwnBins in the kernel)
 
+// allow_lines = false: the one-launch NCHW_SRC form has no SHIFT == 2 instantiation -- rows that are not whole sectors
+// take kShift there at any size (the plan used to return kShiftLines beyond 320 MB, which the fused launch
+// then ran as SHIFT = 0 on a grid sized for 32-bin tiles)
 ForwardPlan plan_forward_gather(int num_rois, int channels, int NB, int nchunks, bool out_nhwc, bool launcher_rest, int groups = 1,
-                                size_t map_bytes_per_xcd = 0)
+                                size_t map_bytes_per_xcd = 0, bool allow_lines = true)
 {
     const int base_dbg = (g_tune.fwd_dbg & ~0xe0) | (launcher_rest ? 32 : 0);   // bits 5-7 are the host's
     const int ntiles = ceil_div(NB, kTileBins);
@@ -465,7 +468,7 @@ ForwardPlan plan_forward_gather(int num_rois, int channels, int NB, int nchunks,
     // two 120 x 160 maps, 11 x 83: R = 2048 (456 MB) 172 / 141, R = 4096 (913 MB) 358 / 272; C = 256, 11 x 50, R = 1024 (550 MB)
     // 251 / 176; 11 x 100, R = 600 (645 MB) 215 / 183.  Around the cache's size it is a draw or worse (267-275 MB: 80 / 87,
     // 73 / 87, 104 / 93, 76 / 83; 322-334 MB: 105 / 97, 112 / 108): from 320 MB up.
-    if (NB % 16 != 0 && (g_tune.fwd_shift_lines == 2 ||
+    if (allow_lines && NB % 16 != 0 && (g_tune.fwd_shift_lines == 2 ||
                          (g_tune.fwd_shift_lines == 1 && (size_t)num_rois * channels * NB * sizeof(float) > ((size_t)320 << 20)))) {
         const int nt = ceil_div(NB, kTileBins - 32);
         return {FwdKernel::kShiftLines, tiled_grid((long)num_rois * nt, nchunks, g_tune.shift_lines_wgs_per_cu), nt, base_dbg};
@@ -516,12 +519,14 @@ struct LauncherArena {
     size_t bytes = 0;
     unsigned long long last_use = 0;
     bool pinned = false;   // handed out during a stream capture: a graph replays with this address
+    unsigned long long capture_id = 0;   // ... the capture that pinned it: later calls of the SAME capture may reuse it
     std::mutex in_use;     // held by the lease of the call that is enqueuing on this buffer
 };
-constexpr int kMaxArenas = 16;
+constexpr int kMaxArenas = 64;   // pinned entries keep their slot for the life of the process (documented in the header)
 std::mutex g_table_mutex;
 LauncherArena g_arenas[kMaxArenas];
 unsigned long long g_arena_clock = 0;
+std::atomic<unsigned long long> g_transient_calls{0};
 
 // A buffer of at least `bytes` for launches on `stream`, held under its entry's lock until give_back().
 struct ScratchLease {
@@ -545,22 +550,43 @@ ScratchLease launcher_scratch(hipStream_t stream, size_t bytes)
     int dev = 0;
     if ((L.err = hipGetDevice(&dev)) != hipSuccess) return L;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    unsigned long long cap_id = 0;
+    const bool capturing = hipStreamGetCaptureInfo(stream, &cap, &cap_id) == hipSuccess && cap != hipStreamCaptureStatusNone;
     auto take_transient = [&]() {
         L.err = hipMallocAsync(&L.ptr, bytes, stream);
         L.transient = L.err == hipSuccess;
         if (!L.transient) L.ptr = nullptr;
+        g_transient_calls.fetch_add(1, std::memory_order_relaxed);
     };
     std::unique_lock<std::mutex> table(g_table_mutex);
-    // the stream's own, unpinned entry (a pinned one belongs to its graph)
     LauncherArena* a = nullptr;
-    for (LauncherArena& e : g_arenas)
-        if (e.used && !e.pinned && e.device == dev && e.stream == stream) a = &e;
+    std::unique_lock<std::mutex> mine;
+    for (;;) {
+        // the stream's own entry: the one THIS capture pinned earlier (a second launcher call inside one capture reuses
+        // it instead of taking mem-alloc nodes), else its unpinned one (a pinned one belongs to its graph)
+        a = nullptr;
+        for (LauncherArena& e : g_arenas)
+            if (e.used && e.device == dev && e.stream == stream && capturing && e.pinned && e.capture_id == cap_id && e.bytes >= bytes)
+                a = &e;
+        if (!a)
+            for (LauncherArena& e : g_arenas)
+                if (e.used && !e.pinned && e.device == dev && e.stream == stream) a = &e;
+        if (!a) break;
+        mine = std::unique_lock<std::mutex>(a->in_use, std::try_to_lock);
+        if (mine.owns_lock()) break;
+        // another thread is enqueuing on this entry: wait for it WITHOUT the table lock (holding it stalled
+        // every other stream's look-up), then look the entry up again -- it may have grown, been pinned or evicted
+        table.unlock();
+        { std::lock_guard<std::mutex> wait(a->in_use); }   // (the entries are static: the mutex outlives any eviction)
+        table.lock();
+    }
     if (a) {
-        std::unique_lock<std::mutex> mine(a->in_use);   // (waits for a call that is enqueuing on this entry)
         if (a->bytes >= bytes) {
             a->last_use = ++g_arena_clock;
-            if (capturing) a->pinned = true;            // this graph's from now on
+            if (capturing && !a->pinned) {             // this graph's from now on
+                a->pinned = true;
+                a->capture_id = cap_id;
+            }
             L.ptr = a->ptr;
             L.lock = std::move(mine);
             return L;
@@ -597,7 +623,6 @@ ScratchLease launcher_scratch(hipStream_t stream, size_t bytes)
     LauncherArena* slot = nullptr;
     for (LauncherArena& e : g_arenas)
         if (!e.used && !slot) slot = &e;
-    std::unique_lock<std::mutex> mine;
     if (slot) {
         mine = std::unique_lock<std::mutex>(slot->in_use);
     } else {
@@ -636,7 +661,7 @@ ScratchLease launcher_scratch(hipStream_t stream, size_t bytes)
 // ====================================================================================
 extern "C" {
 
-const char* rroi_align_hip_version(void) { return "rroi_align_hip 0.7.0 gfx950"; }
+const char* rroi_align_hip_version(void) { return "rroi_align_hip 0.8.0 gfx950"; }
 
 size_t rroi_align_forward_workspace_bytes(int batch_size, int channels, int height, int width,
                                           int num_rois, int feature_layout)
@@ -738,7 +763,8 @@ static int forward_impl(const float* features, int feature_layout, int top_layou
     if (fused) {
         if (!(stages & RROI_STAGE_GATHER)) return 1;  // one launch, run under the gather stage
         const int nchunks = ceil_div(channels, kChunk);
-        const ForwardPlan plan = plan_forward_gather(num_rois, channels, NB, nchunks, false, false);
+        const ForwardPlan plan = plan_forward_gather(num_rois, channels, NB, nchunks, false, false, 1, 0, /*allow_lines*/ false);
+        if (plan.kernel != FwdKernel::kShift && plan.kernel != FwdKernel::kStrided) return 0;   // the two forms NCHW_SRC has
         if ((long)num_rois * plan.ntiles >= (1L << 31)) return 0;
         const unsigned HWu = (unsigned)height * (unsigned)width;
         SliceLayout lay;
@@ -1429,15 +1455,41 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
     return launch_status();
 }
 
-int rroi_align_release_launcher_scratch(void)
+int rroi_align_set_trig_recipe_hip(int recipe) { return recipe == RROI_TRIG_DOUBLE ? 1 : 0; }   // deprecated shim, see the header
+int rroi_align_get_trig_recipe_hip(void) { return RROI_TRIG_DOUBLE; }
+
+int rroi_align_launcher_scratch_stats(int* in_use, int* pinned, int* capacity, unsigned long long* transient_calls)
 {
     std::lock_guard<std::mutex> table(g_table_mutex);
+    int u = 0, p = 0;
+    for (const LauncherArena& a : g_arenas) {
+        u += a.used ? 1 : 0;
+        p += a.used && a.pinned ? 1 : 0;
+    }
+    if (in_use) *in_use = u;
+    if (pinned) *pinned = p;
+    if (capacity) *capacity = kMaxArenas;
+    if (transient_calls) *transient_calls = g_transient_calls.load(std::memory_order_relaxed);
+    return 1;
+}
+
+int rroi_align_release_launcher_scratch(void)
+{
+    std::unique_lock<std::mutex> table(g_table_mutex);
     int cur = 0;
     (void)hipGetDevice(&cur);
     hipError_t e = hipSuccess;
-    for (LauncherArena& a : g_arenas) {
+    for (int i = 0; i < kMaxArenas; ++i) {
+        LauncherArena& a = g_arenas[i];
         if (!a.used || a.pinned) continue;   // pinned: a graph replays with this address, it lives as long as the process
-        std::lock_guard<std::mutex> mine(a.in_use);   // (a call that is enqueuing on it finishes first)
+        std::unique_lock<std::mutex> mine(a.in_use, std::try_to_lock);
+        if (!mine.owns_lock()) {   // a call is enqueuing on it: wait without the table lock, then look at the entry again
+            table.unlock();
+            { std::lock_guard<std::mutex> wait(a.in_use); }
+            table.lock();
+            --i;
+            continue;
+        }
         (void)hipSetDevice(a.device);
         const hipError_t ei = hipFree(a.ptr);  // synchronous: the buffers' streams may be gone
         if (ei != hipSuccess) e = ei;

@@ -84,6 +84,8 @@ _lib.RROIAlignBackwardLaucher.restype = _i
 _lib.RROIAlignBackwardLaucher.argtypes = [_vp, _f, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.rroi_align_release_launcher_scratch.restype = _i
 _lib.rroi_align_release_launcher_scratch.argtypes = []
+_lib.rroi_align_launcher_scratch_stats.restype = _i
+_lib.rroi_align_launcher_scratch_stats.argtypes = [_vp, _vp, _vp, _vp]
 
 EXPORTS = (
     "RROIAlignForwardLaucher", "RROIAlignBackwardLaucher", "rroi_align_forward_hip",
@@ -93,7 +95,8 @@ EXPORTS = (
     "rroi_ctc_greedy_decode_hip", "rroi_align_backward_layout_hip", "rroi_align_forward_layout_hip",
     "rroi_align_gt_quads_to_rois_hip", "rroi_rbox_decode_hip", "rroi_nms_merge_host",
     "rroi_align_release_launcher_scratch", "rroi_align_bin_centres_trig_hip", "rroi_nms_record_format",
-    "rroi_align_write_probe_hip",
+    "rroi_align_write_probe_hip", "rroi_align_launcher_scratch_stats",
+    "rroi_align_set_trig_recipe_hip", "rroi_align_get_trig_recipe_hip",   # deprecated shims (refuse TRIG_FP32)
 )
 
 
@@ -166,6 +169,13 @@ def release_workspaces() -> None:
     with _scratch_lock:
         _scratch.clear()
     _check(_lib.rroi_align_release_launcher_scratch(), "rroi_align_release_launcher_scratch")
+
+
+def launcher_scratch_stats() -> dict:
+    """State of the library's scratch table for the reference-ABI launchers (see the header)."""
+    u, p, c, t = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_ulonglong()
+    _lib.rroi_align_launcher_scratch_stats(ctypes.byref(u), ctypes.byref(p), ctypes.byref(c), ctypes.byref(t))
+    return {"in_use": u.value, "pinned": p.value, "capacity": c.value, "transient_calls": t.value}
 
 
 def _require_cuda_f32(t: torch.Tensor, name: str) -> None:

@@ -62,10 +62,21 @@ int RROIAlignBackwardLaucher(const float* top_diff, const float spatial_scale,
  * life of the process, on any stream, concurrently with eager calls (replays of ONE graph must of course be ordered
  * among themselves, as for any graph that writes its own scratch).  To capture with memory the GRAPH owns from the
  * start, capture the first call on a stream that has no buffer yet (or one that is too small): that call allocates
- * inside the capture.
+ * inside the capture.  Further launcher calls inside the SAME capture reuse the buffer that capture pinned when it is
+ * large enough (0.8.0; before, each took stream-ordered memory of its own).
+ * Limits: the table has 64 entries; a pinned buffer keeps its entry for the life of the process, an unpinned one is
+ * evicted least-recently-used first.  With every entry pinned (64 captures on 64 streams) a call that finds nothing
+ * cached takes stream-ordered memory for that call alone (hipMallocAsync / hipFreeAsync around its launches): correct,
+ * slower, and not silent -- rroi_align_launcher_scratch_stats() reports the table's state.
+ * A thread that waits for another thread's enqueue on the SAME (device, stream) entry does so without the table lock:
+ * calls on different streams never serialise each other.
  * This frees every buffer no graph holds (synchronously); they are re-created on demand.
  * Returns 1 / -hipError. */
 int rroi_align_release_launcher_scratch(void);
+/* State of the launcher scratch table: *in_use = entries that hold a buffer, *pinned = those a graph owns,
+ * *capacity = 64, *transient_calls = launcher calls served by stream-ordered memory of their own so far (no entry to
+ * cache in, or a capture that found no buffer large enough).  Any pointer may be NULL.  Returns 1. */
+int rroi_align_launcher_scratch_stats(int* in_use, int* pinned, int* capacity, unsigned long long* transient_calls);
 
 /* ------------------------------------------------------------------------- *
  * 2. The MI355X-native entry points used by the Python surface
@@ -270,7 +281,14 @@ int rroi_align_sincos_probe_hip(const float* angle_deg, int n, float* out, void*
  * a write of non-zero, non-constant data reaches on the box (zeros are written faster on this chip). */
 int rroi_align_write_probe_hip(float* out, size_t num_floats, void* stream);
 
-/* Identification: "rroi_align_hip <version> gfx950" (0.7.0: per-call trig recipe, device-wide setter removed). */
+/* DEPRECATED shims of the per-device setter / getter of versions 0.5-0.6 (removed in 0.7.0 without one, ADVICE r05;
+ * they go away in 0.9): the recipe travels in `path` now.  set: 1 for RROI_TRIG_DOUBLE (what every call without the
+ * RROI_PATH_TRIG_FP32 bit runs: nothing to do), 0 for RROI_TRIG_FP32 or anything else -- the library has no device-wide
+ * state left to change, so the request is REFUSED rather than silently ignored; get: RROI_TRIG_DOUBLE. */
+int rroi_align_set_trig_recipe_hip(int recipe);
+int rroi_align_get_trig_recipe_hip(void);
+
+/* Identification: "rroi_align_hip <version> gfx950" (0.7.0: per-call trig recipe, device-wide setter removed; 0.8.0: launcher scratch reused within a capture, table of 64, stats). */
 const char* rroi_align_hip_version(void);
 
 #ifdef __cplusplus

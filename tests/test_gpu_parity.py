@@ -131,11 +131,13 @@ def test_forward_xcd_groups(ext, oracle, case):
 
 @pytest.mark.parametrize("pw", [96, 83, 50])
 def test_forward_beyond_the_cache(ext, oracle, pw):
-    """Crops beyond the 256 MB memory-side cache.  Rows of whole sectors (11 x 96, 297 MB) keep their XCD groups there;
-    rows that are not (11 x 83: 330 MB at C = 64; 11 x 50 at C = 136 -- a last chunk of eight channels --: 335 MB) go back
-    to one group and, from 320 MB up, take the LINE-aligned form (SHIFT == 2: a tile stores 32 bins of the 64 it gathers,
-    every store a whole 128-byte line).  The tiled path against the direct kernel on all of it, and against the oracle
-    on a sample of the ROIs."""
+    """Crops beyond the 256 MB memory-side cache.  XCD groups are kept at ANY size (forward_groups: no size limit), for rows
+    of whole sectors (11 x 96, 297 MB) and for rows that are not (11 x 83: 330 MB at C = 64; 11 x 50 at C = 136 -- a last
+    chunk of eight channels --: 335 MB); the latter take, from 320 MB up, the LINE-aligned form (SHIFT == 2: a tile stores
+    32 bins of the 64 it gathers, every store a whole 128-byte line).  The tiled path against the direct kernel on all of
+    it, and against the oracle on a sample of the ROIs.  ADVICE r05: the ONE-LAUNCH form (RROI_PATH_FUSED) has no
+    line-aligned instantiation -- on such crops it must run its SHIFT form (it used to launch SHIFT = 0 on a grid sized for
+    32-bin tiles: a row's last 16-byte store ran into the next channel's first bins when NB % 4 != 0)."""
     rng = np.random.default_rng(99)
     B, C, H, W, R, ph = 2, 64, 60, 80, 1100 if pw == 96 else 1480, 11
     if pw == 50:
@@ -152,6 +154,9 @@ def test_forward_beyond_the_cache(ext, oracle, pw):
     pick = np.sort(rng.choice(R, 48, replace=False))
     want = oracle.forward_c(f, r[pick], ph, pw, 0.25, threads=8)
     assert eq(got[torch.from_numpy(pick).cuda()].cpu().numpy(), want)
+    del got
+    fused = ext.forward(Fd, Rd, ph, pw, 0.25, path=ext.PATH_FUSED)
+    assert torch.equal(fused.view(torch.int32), direct.view(torch.int32))
 
 
 def test_forward_tiny_maps_every_path(ext, oracle):
@@ -684,7 +689,7 @@ def test_reference_launchers_reuse_their_scratch_and_accumulate(ext, oracle):
                                                     big.data_ptr(), None, None, side.cuda_stream) == 1
         side.synchronize()
     assert eq(big.cpu().numpy(), oracle.forward_c(f2, r2, 8, 64, 0.25))
-    others = [torch.cuda.Stream() for _ in range(18)]          # more streams than the library keeps buffers for
+    others = [torch.cuda.Stream() for _ in range(ext.launcher_scratch_stats()["capacity"] + 4)]   # more streams than the library keeps buffers for
     for s_ in others:
         with torch.cuda.stream(s_):
             assert ext._lib.RROIAlignForwardLaucher(F.data_ptr(), 0.25, 96, 160, 160, 64, 8, 64, Rr.data_ptr(),
@@ -704,6 +709,42 @@ def test_reference_launchers_reuse_their_scratch_and_accumulate(ext, oracle):
                                             out.data_ptr(), None, None, stream()) == 1
     torch.cuda.synchronize()
     assert torch.equal(out, want_out)
+
+
+def test_launcher_scratch_is_reused_within_one_capture(ext, oracle):
+    """a buffer handed out during a capture is pinned (graph-exclusive) -- but further launcher calls inside the
+    SAME capture reuse it (same capture id) instead of taking hipMallocAsync / hipFreeAsync nodes each; the deprecated
+    per-device trig setter is a shim that refuses what it can no longer do."""
+    f, r = Wk.bench_inputs(R=160, C=64, seed=35)
+    F, Rr = dev(f), dev(r)
+    outs = [torch.empty((160, 64, 8, 64), device="cuda") for _ in range(3)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+
+    def call(o):
+        assert ext._lib.RROIAlignForwardLaucher(F.data_ptr(), 0.25, 160, 160, 160, 64, 8, 64, Rr.data_ptr(), o.data_ptr(), None, None,
+                                                side.cuda_stream) == 1
+    # (160 ROIs: above the forward's two-launch crossover of 3.8 M output elements -- fewer take the one-launch patch kernel, no scratch)
+    with torch.cuda.stream(side):
+        call(outs[0])                    # creates the side stream's scratch
+        side.synchronize()
+        before = ext.launcher_scratch_stats()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for o in outs:
+                call(o)
+        after = ext.launcher_scratch_stats()
+    torch.cuda.current_stream().wait_stream(side)
+    assert after["pinned"] == before["pinned"] + 1 and after["transient_calls"] == before["transient_calls"], (before, after)
+    for o in outs:
+        o.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    want = oracle.forward_c(f, r, 8, 64, 0.25, threads=8)
+    for o in outs:
+        assert eq(o.cpu().numpy(), want)
+    assert ext._lib.rroi_align_set_trig_recipe_hip(ext.TRIG_DOUBLE) == 1
+    assert ext._lib.rroi_align_set_trig_recipe_hip(ext.TRIG_FP32) == 0 and ext._lib.rroi_align_get_trig_recipe_hip() == ext.TRIG_DOUBLE
 
 
 def test_reference_launchers_from_several_threads(ext, oracle):
