@@ -48,6 +48,8 @@ import time
 import numpy as np
 import torch
 
+from bench_legs import beyond_cache, mixed_layout, train_regime, train_step
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "fots.pytorch_amd"))
 
@@ -121,129 +123,6 @@ def cpu_baseline(feats, rois):
         "ms_per_step": round(best * 1e3, 2),
         "backward": backward,
     }, touched
-
-
-def train_regime(ext, dev, event_loop):
-    """the reference's OWN training call (src/ocr_process.py:259-267: pooled_height 11,
-    pooled_width = ceil(11 * max w / h) -- any integer), on its 64-channel 1/4 map: forward and backward per shape
-    with algorithmic bytes and the fraction of the 8 TB/s peak.  Not part of `value`."""
-    B, C, H, W, scale = 2, 64, 120, 160, 0.25
-    stream = torch.cuda.current_stream().cuda_stream
-    rows = {}
-
-    def settled(fn, timed):
-        """event_loop after ~20 ms of the same call: every shape starts behind host-side set-up (uploads, allocations) and
-        the first few hundred calls after such a pause run ~2.5 us slower than the ones that follow (tools/merge_ab.py and
-        tools/groups_ab.py time every form twice for that reason: 35.4 then 32.8 us for the same launch)"""
-        per_call_ms = max(event_loop(fn, 5, 30), 1e-3)
-        # median of three loops: at R = 32 a call is 8-9 us of GPU time and the host is barely ahead of it, so one host-side
-        # hiccup inside a 2 ms loop shows (seen once: 14.2 us for a call that is 7.8 in every other run)
-        return sorted([event_loop(fn, int(20.0 / per_call_ms) + 1, timed), event_loop(fn, 0, timed), event_loop(fn, 0, timed)])[1]
-    for PW in (83, 100, 96):          # 11 x 96 is the aligned shape the SHIFT kernels are held against
-        for R in (32, 512):
-            rng = np.random.default_rng(1000 + R + PW)
-            feats = torch.from_numpy(rng.standard_normal((B, C, H, W), dtype=np.float32)).to(dev)
-            h = rng.uniform(16, 64, R)
-            rois = torch.from_numpy(np.stack([rng.integers(0, B, R), rng.uniform(0, 4 * W, R), rng.uniform(0, 4 * H, R), h,
-                                              h * rng.uniform(2, PW / 11.0, R), rng.uniform(-45, 45, R)], 1).astype(np.float32)).to(dev)
-            out = torch.empty((R, C, 11, PW), dtype=torch.float32, device=dev)
-            gout = torch.randn_like(out)
-            gin = torch.empty_like(feats)
-            nf = ext._lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, ext.LAYOUT_NCHW)
-            nb = ext._lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, 11, PW)
-            ws = torch.empty(max(nf, nb, 1), dtype=torch.uint8, device=dev)
-
-            def fwd():
-                st = ext._lib.rroi_align_forward_hip(feats.data_ptr(), ext.LAYOUT_NCHW, scale, B, R, H, W, C, 11, PW,
-                                                     rois.data_ptr(), out.data_ptr(), ws.data_ptr(), nf, ext.PATH_AUTO, stream)
-                if st != 1:
-                    raise RuntimeError(f"train_regime forward -> {st}")
-
-            def bwd():
-                st = ext._lib.rroi_align_backward_hip(gout.data_ptr(), scale, B, R, H, W, C, 11, PW, rois.data_ptr(),
-                                                      gin.data_ptr(), ws.data_ptr(), nb, ext.PATH_AUTO, stream)
-                if st != 1:
-                    raise RuntimeError(f"train_regime backward -> {st}")
-            f_ms, b_ms = settled(fwd, 200), settled(bwd, 100)
-            # the same pair with channels-last tensors at both ends (what the callers' modules hand over when the backbone
-            # runs channels_last, VERDICT r04 item 3): features consumed in place, crops / gradients channels-last
-            feats_cl = feats.contiguous(memory_format=torch.channels_last)
-            out_cl = torch.empty((R, C, 11, PW), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
-            gout_cl = gout.contiguous(memory_format=torch.channels_last)
-            nf_cl = ext._lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, ext.LAYOUT_NHWC)
-            ws_cl = torch.empty(max(nf_cl, nb, 1), dtype=torch.uint8, device=dev)
-
-            def fwd_cl():
-                st = ext._lib.rroi_align_forward_layout_hip(feats_cl.data_ptr(), ext.LAYOUT_NHWC, ext.LAYOUT_NHWC, scale, B, R, H, W, C,
-                                                            11, PW, rois.data_ptr(), out_cl.data_ptr(), ws_cl.data_ptr(), nf_cl,
-                                                            ext.PATH_AUTO, stream)
-                if st != 1:
-                    raise RuntimeError(f"train_regime forward (channels-last) -> {st}")
-
-            def bwd_cl():
-                st = ext._lib.rroi_align_backward_layout_hip(gout_cl.data_ptr(), ext.LAYOUT_NHWC, ext.LAYOUT_NHWC, scale, B, R, H, W, C,
-                                                             11, PW, rois.data_ptr(), gin.data_ptr(), ws_cl.data_ptr(), nb,
-                                                             ext.PATH_AUTO, stream)
-                if st != 1:
-                    raise RuntimeError(f"train_regime backward (channels-last) -> {st}")
-            fcl_ms, bcl_ms = settled(fwd_cl, 200), settled(bwd_cl, 100)
-            del feats_cl, out_cl, gout_cl, ws_cl
-            # algorithmic bytes: crops + rois + the map once (an upper bound of the touched pixels; at R = 32 most of the
-            # map is not touched, so the forward's fraction is an overestimate there -- the call still relays it out)
-            crops, fmap = R * C * 11 * PW * 4, B * C * H * W * 4
-            fb, bb = crops + R * 24 + fmap, crops + R * 24 + fmap
-            rows["11x%d_R%d" % (PW, R)] = {
-                "forward_us": round(f_ms * 1e3, 2), "backward_us": round(b_ms * 1e3, 2),
-                "forward_algorithmic_bytes": fb, "backward_algorithmic_bytes": bb,
-                "forward_frac_of_peak": round(fb / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "backward_frac_of_peak": round(bb / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "forward_us_channels_last": round(fcl_ms * 1e3, 2), "backward_us_channels_last": round(bcl_ms * 1e3, 2),
-                "backward_frac_of_peak_channels_last": round(bb / (bcl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            del feats, rois, out, gout, gin, ws
-    for PW in (83, 100):
-        for R in (32, 512):
-            rows["11x%d_R%d" % (PW, R)]["forward_vs_aligned_11x96"] = round(
-                rows["11x%d_R%d" % (PW, R)]["forward_us"] / rows["11x96_R%d" % R]["forward_us"] / (PW / 96.0), 3)
-    rows["what"] = ("the reference's training call (src/ocr_process.py:259-267): %d images of %d x %d x %d, pooled 11 x PW, "
-                    "R ROIs over the images, PATH_AUTO, 200 / 100 back-to-back calls between HIP events after ~20 ms of the same call, median of three such loops; bytes = crops + "
-                    "rois + the whole map once; forward_vs_aligned_11x96 = time per output byte against the 11 x 96 shape "
-                    "(rows of whole 64-byte sectors) at the same R; *_channels_last = the same calls with channels-last features, crops "
-                    "and gradients (no relayout on either side)" % (B, C, H, W))
-    return rows
-
-
-def beyond_cache(ext, dev, event_loop):
-    """crops LARGER than the 256 MB memory-side cache, forward only -- rows of whole 64-byte sectors
-    (configs[1]'s pooled size with twice the ROIs; the 64-channel training shape at 11 x 96) and rows that are not (the
-    line-aligned windows of round 5: C = 256, 11 x 100 -- the shape the verdict names -- and C = 64, 11 x 83).  Not part of
-    `value`."""
-    stream = torch.cuda.current_stream().cuda_stream
-    rows = {}
-    for (tag, B, C, H, W, R, PH, PW) in (("C256_8x64_R1024", 1, 256, 160, 160, 1024, 8, 64), ("C256_11x100_R600", 1, 256, 160, 160, 600, 11, 100),
-                                         ("C64_11x96_R2048", 2, 64, 120, 160, 2048, 11, 96), ("C64_11x83_R2048", 2, 64, 120, 160, 2048, 11, 83)):
-        rng = np.random.default_rng(1000 + R + PW)
-        feats = torch.from_numpy(rng.standard_normal((B, C, H, W), dtype=np.float32)).to(dev)
-        h = rng.uniform(16, 64, R)
-        rois = torch.from_numpy(np.stack([rng.integers(0, B, R), rng.uniform(0, 4 * W, R), rng.uniform(0, 4 * H, R), h,
-                                          h * rng.uniform(2, PW / float(PH), R), rng.uniform(-45, 45, R)], 1).astype(np.float32)).to(dev)
-        out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=dev)
-        nf = ext._lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, ext.LAYOUT_NCHW)
-        ws = torch.empty(max(nf, 1), dtype=torch.uint8, device=dev)
-
-        def fwd():
-            st = ext._lib.rroi_align_forward_hip(feats.data_ptr(), ext.LAYOUT_NCHW, 0.25, B, R, H, W, C, PH, PW, rois.data_ptr(),
-                                                 out.data_ptr(), ws.data_ptr(), nf, ext.PATH_AUTO, stream)
-            if st != 1:
-                raise RuntimeError(f"beyond_cache forward -> {st}")
-        ms = sorted(event_loop(fwd, 30 if i == 0 else 0, 60) for i in range(3))[1]
-        crops = R * C * PH * PW * 4
-        rows[tag] = {"forward_us": round(ms * 1e3, 1), "crops_MB": round(crops / 1e6, 1),
-                     "crops_TBps": round(crops / (ms * 1e-3) / 1e12, 2), "rows_are_whole_sectors": PH * PW % 16 == 0}
-        del feats, rois, out, ws
-    rows["what"] = ("forward calls whose crops exceed the 256 MB memory-side cache (PATH_AUTO, NCHW, median of three loops of 60 "
-                    "back-to-back calls): bytes of crops / time.  Rows that are not whole sectors take the line-aligned windows "
-                    "(32 own bins of 64 gathered) there; round 4: 2.2-3.0 TB/s")
-    return rows
 
 
 def _free_port():
@@ -575,6 +454,14 @@ def run(args):
                 raise RuntimeError(f"rroi_align_backward_layout_hip -> {st}")
         bwd_cl_ms = event_loop(bwd_cl, 10, 50)
         del gout, gout_cl, ws_b, gin
+    # ... and in the hand-off the reference's pipeline can reach (round 6): NCHW features / gradient, channels-last crops / top_diff
+    mixed = None
+    if world == 1 and os.environ.get("RROI_BENCH_SENSITIVITY", "1") == "1":
+        try:
+            mixed = mixed_layout(ext, dev, event_loop, c, feats, rois)
+            launch(ext.STAGE_ALL)
+        except Exception as e:
+            mixed = {"error": repr(e)[:300]}
 
     # what ONE call costs when it is not the 1,000th of a back-to-back run -- after >= 2 ms of an
     # idle GPU and after unrelated kernels (an elementwise pass over 64 MB and a 2048^3 matrix product) have had the caches:
@@ -618,6 +505,13 @@ def run(args):
             train = train_regime(ext, dev, event_loop)
         except Exception as e:
             train = {"error": repr(e)[:300]}
+
+    tstep = None
+    if world == 1 and os.environ.get("RROI_BENCH_TRAIN", "1") == "1":
+        try:
+            tstep = train_step(ext, dev, event_loop)
+        except Exception as e:
+            tstep = {"error": repr(e)[:300]}
 
     big = None
     if world == 1 and os.environ.get("RROI_BENCH_BIG", "1") == "1":
@@ -811,6 +705,7 @@ def run(args):
                 "frac_of_peak_whole_call": round((R * c["C"] * c["PH"] * c["PW"] * 4 + c["C"] * c["H"] * c["W"] * 4 + R * 24)
                                                  / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "ms_per_call_channels_last": round(bwd_cl_ms, 5),  # top_diff and the feature gradient both channels_last
+                "mixed": mixed,   # NCHW features / feature gradient, channels-last crops / top_diff (+ the forward of that pair)
                 # per-kernel durations and fabric traffic of the same call: rocprofv3 kernel trace + separate --pmc passes
                 # (tools/profile_bwd.sh -> profiles/bwd_traffic.json), collected once per round, not in this run
                 "roofline": None if bwd_prof is None else dict(
@@ -821,6 +716,7 @@ def run(args):
                         bwd_prof["traffic_bytes_per_call"]
                         / (R * c["C"] * c["PH"] * c["PW"] * 4 + c["C"] * c["H"] * c["W"] * 4 + R * 24), 3))},
             "train_regime": train,
+            "train_step": tstep,
             "beyond_cache": big,
             "e2e": e2e,
         },

@@ -513,6 +513,46 @@ def test_channels_last_pipeline_through_autograd(ext, oracle):
 
 
 @pytest.mark.parametrize("name", ["mid_c64", "batch3", "train_11xceil"])
+def test_mixed_layout_handoff(ext, oracle, name):
+    """the hand-off the reference's pipeline can reach -- NCHW features and NCHW feature gradient
+    (what its backbone emits and expects, tools/models.py:387-457) with channels-last crops and top_diff.  Through the
+    C-ABI (rroi_align_forward_layout_hip(NCHW, NHWC), rroi_align_backward_layout_hip(NHWC, NCHW)) and through the
+    module with a channels-last consumer behind it: crops bit-exact against the oracle, gradient max-abs <= 1e-4."""
+    from rroi_align.modules.rroi_align import _RRoiAlign
+    f, r, ph, pw, s = SHAPES[name]()
+    B, C, H, W = f.shape
+    R = len(r)
+    want = oracle.forward_c(f, r, ph, pw, s, threads=8)
+    gout = np.random.default_rng(4).standard_normal(want.shape).astype(np.float32)
+    gwant = oracle.backward_c(gout, r, f.shape, s)
+    stream = torch.cuda.current_stream().cuda_stream
+    F, Rr = dev(f), dev(r)
+    out = torch.empty((R, C, ph, pw), device="cuda").contiguous(memory_format=torch.channels_last)
+    G = dev(gout).contiguous(memory_format=torch.channels_last)
+    gin = torch.full(f.shape, float("nan"), device="cuda")
+    nf = ext._lib.rroi_align_forward_workspace_bytes(B, C, H, W, R, ext.LAYOUT_NCHW)
+    nb = ext._lib.rroi_align_backward_workspace_bytes(B, C, H, W, R, ph, pw)
+    ws = torch.empty(max(nf, nb), dtype=torch.uint8, device="cuda")
+    for path in (ext.PATH_AUTO, ext.PATH_TILED):
+        out.fill_(float("nan"))
+        assert ext._lib.rroi_align_forward_layout_hip(F.data_ptr(), ext.LAYOUT_NCHW, ext.LAYOUT_NHWC, s, B, R, H, W, C, ph, pw,
+                                                      Rr.data_ptr(), out.data_ptr(), ws.data_ptr(), nf, path, stream) == 1
+        assert out.is_contiguous(memory_format=torch.channels_last) and eq(out.cpu().numpy(), want)
+    for path in (ext.PATH_AUTO, ext.PATH_TILED, ext.PATH_TILED_LISTS, ext.PATH_TILED_BUCKETS, ext.PATH_TILED_INKERNEL):
+        gin.fill_(float("nan"))
+        assert ext._lib.rroi_align_backward_layout_hip(G.data_ptr(), ext.LAYOUT_NHWC, ext.LAYOUT_NCHW, s, B, R, H, W, C, ph, pw,
+                                                       Rr.data_ptr(), gin.data_ptr(), ws.data_ptr(), nb, path, stream) == 1
+        Wk.check_backward(gin.cpu().numpy(), gwant, f"mixed {name} path {path}")
+    # the module: NCHW features, channels_last_out=True, a consumer whose gradient arrives channels-last
+    feats = dev(f).requires_grad_(True)
+    crops = _RRoiAlign(ph, pw, s, channels_last_out=True)(feats, Rr)
+    assert crops.is_contiguous(memory_format=torch.channels_last) and eq(crops.detach().cpu().numpy(), want)
+    (crops * G).sum().backward()              # d/d crops = G, handed over in G's channels-last storage
+    assert feats.grad.is_contiguous()         # NCHW, the features' own layout
+    Wk.check_backward(feats.grad.cpu().numpy(), gwant, f"mixed {name} autograd")
+
+
+@pytest.mark.parametrize("name", ["mid_c64", "batch3", "train_11xceil"])
 def test_backward_channels_last_grad(ext, oracle, name):
     """grad_output in channels_last storage (a channels_last recognition head) is consumed in place."""
     f, r, ph, pw, s = SHAPES[name]()
