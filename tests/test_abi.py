@@ -155,7 +155,7 @@ def test_python_constants_are_the_headers():
 def test_write_probe_and_trig_recipe_hooks():
     """Round-4 entry points: the bench's write probe fills exactly the floats it is given (values that differ from
     store to store, nothing behind them), refuses misaligned / odd requests.  Round 5: the trig recipe travels in the
-    call (`path | RROI_PATH_TRIG_FP32`), the device-wide setter is gone."""
+    call (`path | RROI_PATH_TRIG_FP32`); the device-wide setter is a deprecated shim without effect."""
     import torch
     from rroi_align._ext import rroi_align as ext
     buf = torch.full((4096 + 8,), float("nan"), device="cuda")
@@ -168,9 +168,12 @@ def test_write_probe_and_trig_recipe_hooks():
     assert ext._lib.rroi_align_write_probe_hip(buf.data_ptr(), 0, st) == 1
     # round 5: the trig recipe is a flag bit of the call's `path` (no device-wide setter any more); unknown flag bits
     # and unknown recipes are refused
-    for gone in ("rroi_align_set_trig_recipe_hip", "rroi_align_get_trig_recipe_hip"):
-        with pytest.raises(AttributeError):
-            getattr(ext._lib, gone)
+    # (0.8.0, ADVICE r05: the setter / getter of 0.5-0.6 are back as DEPRECATED shims that refuse what they can no longer
+    # do -- there is no device-wide state: TRIG_DOUBLE is acknowledged, TRIG_FP32 is refused, the getter says TRIG_DOUBLE)
+    assert ext._lib.rroi_align_set_trig_recipe_hip(ext.TRIG_DOUBLE) == 1
+    assert ext._lib.rroi_align_set_trig_recipe_hip(ext.TRIG_FP32) == 0
+    assert ext._lib.rroi_align_set_trig_recipe_hip(7) == 0
+    assert ext._lib.rroi_align_get_trig_recipe_hip() == ext.TRIG_DOUBLE
     F = torch.randn(1, 4, 16, 16, device="cuda")
     R = torch.tensor([[0, 30, 30, 10, 40, 20.0]], device="cuda")
     a = ext.forward(F, R, 4, 16, 0.25, trig=ext.TRIG_DOUBLE)
