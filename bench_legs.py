@@ -249,6 +249,7 @@ def train_step(ext, dev, event_loop):
     rows["what"] = ("recognition branch of one training step: _RRoiAlign forward (2 x 64 x 128 x 128 map, 32 ROIs, 11 x 96) -> "
                     "FOTSNet.forward_ocr -> CTC -> backward through head and op; head_* = the head alone on crops that are already "
                     "there (fp32, MIOpen, NCHW weights); five interleaved loops of 25 per figure.  The op's two calls are ~30 us of a "
-                    "~4.7 ms step (0.6 %); whether the crops are NCHW or channels-last moves the step by less than the head's own "
-                    "spread, so the callers' modules keep the reference's contract for NCHW features (DESIGN.md 5.5)")
+                    "~4.7 ms step (0.6 %).  Measured on every box so far: channels-last crops make the head (NCHW weights) 70-100 us SLOWER per "
+                    "step -- three times the op's whole cost -- so the callers' modules keep the reference's contract for NCHW features "
+                    "(DESIGN.md 5.5)")
     return rows

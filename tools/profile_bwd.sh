@@ -11,5 +11,5 @@ python3 tools/pmc_summary.py $OUT/traffic > $OUT/pmc_bwd_traffic.md 2>&1
 RROI_BWD_ONLY=1 bash tools/run_pmc.sh "python tools/bwd_profile.py" > /dev/null 2>&1
 cp gpurun_out/pmc/summary.md $OUT/pmc_bwd_kernels.md
 rm -rf $OUT/stats $OUT/traffic gpurun_out/pmc
-python3 tools/bwd_traffic_json.py $OUT/pmc_bwd_traffic.md 5 > $OUT/bwd_traffic.json
+python3 tools/bwd_traffic_json.py $OUT/pmc_bwd_traffic.md 6 > $OUT/bwd_traffic.json
 cat $OUT/pmc_bwd_traffic.md | head -40
