@@ -26,7 +26,7 @@ for _p in (ROOT, os.path.join(ROOT, "fots.pytorch_amd")):
 from fots_e2e.alphabet import ALPHABET  # noqa: E402
 from fots_e2e.hostcpus import cap_torch_threads  # noqa: E402
 from fots_e2e.model import FOTSNet  # noqa: E402
-from fots_e2e.pipeline import batched, infer_image, preprocess, resize_rule  # noqa: E402
+from fots_e2e.pipeline import batched, infer_batch, infer_image, preprocess, resize_rule  # noqa: E402
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
 from e2e_inputs import synthetic_boxes, synthetic_detector_maps  # noqa: E402  (input generators, not product)
 from fots_e2e.weights import deterministic_init  # noqa: E402
@@ -129,6 +129,36 @@ def measure(device, reps=5, channels_last=False):
             out[name]["chain_images_per_s"] = round(1.0 / float(np.median(per_image)), 2)
             out[name]["chain_images_per_s_mean"] = round(len(per_image) / wall, 2)
             out[name]["chain_boxes_per_image"] = round(nbox / len(per_image), 1)
+    # ---- round 6: the same chain over BATCHES of images (`infer_batch`: one pass of the network, one RoIRotate launch and
+    # one set of head launches for the words of all images of the batch) -- throughput mode; the reference's loop has none
+    IMAGES_PER_BATCH = 8
+    with torch.no_grad():
+        order = [i % len(ims) for i in range(2 * IMAGES_PER_BATCH)]        # two different batches: every image at least once
+        groups = [order[i:i + IMAGES_PER_BATCH] for i in range(0, len(order), IMAGES_PER_BATCH)]
+
+        def chain_batch(g):
+            stacked = tuple(torch.stack([maps[i][j] for i in g]) for j in range(3))
+            return infer_batch(net, conv, [ims[i] for i in g], detector=lambda _x: stacked)
+        for g in groups:
+            chain_batch(g)                                     # warm-up
+        per_batch, nbox = [], 0
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(max(1, min(reps, 3))):
+            for g in groups:
+                t1 = time.perf_counter()
+                r = chain_batch(g)
+                torch.cuda.synchronize(device)
+                per_batch.append(time.perf_counter() - t1)
+                nbox += sum(len(b) for b, _t in r)
+        wall = time.perf_counter() - t0
+        out["image_batch"] = {"images_per_batch": IMAGES_PER_BATCH,
+                              "chain_images_per_s": round(IMAGES_PER_BATCH / float(np.median(per_batch)), 2),
+                              "chain_images_per_s_mean": round(IMAGES_PER_BATCH * len(per_batch) / wall, 2),
+                              "chain_boxes_per_image": round(nbox / (IMAGES_PER_BATCH * len(per_batch)), 1),
+                              "what": "infer_batch: %d images per pass of the network (uploads and preprocessing included), "
+                                      "get_boxes per image behind one synchronisation, ONE RoIRotate launch for the words of all "
+                                      "images (the op's batch index), the head per pooled-width bucket across the images" % IMAGES_PER_BATCH}
     out["chain"] = ("chain_*: preprocess + net + rroi_align.nms.get_boxes on the device maps (synthetic trained-detector "
                     "maps injected for the three head outputs: random weights pass no box) + recognition of the boxes "
                     "get_boxes returned; host synchronisations per image on the batched path: the read-back of the "

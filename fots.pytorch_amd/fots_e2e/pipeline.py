@@ -44,7 +44,10 @@ def resize_rule(h0, w0, max_size=1585152, scale_up=False):
 def preprocess(im_u8, device):
     """(H0, W0, 3) uint8 -> (1, 3, H, W) fp32 = resized / 128 - 1 (test.py:77-83).  The resize is
     half-pixel bilinear like cv2.resize's default, done on the device."""
-    t = torch.as_tensor(im_u8).to(device=device, dtype=torch.float32).permute(2, 0, 1).unsqueeze(0)
+    # the BYTES go up (a quarter of the fp32 image) and are widened on the device: `.to(device, dtype)` in one step converts
+    # on the host first -- a parallel region of torch's intra-op pool per image, whose spinning workers are what a
+    # CPU-quota'd container gets throttled for (hostcpus.py; round 6: batches of images took 36 or 70 ms at random)
+    t = torch.as_tensor(im_u8).to(device=device).to(torch.float32).permute(2, 0, 1).unsqueeze(0)
     h, w = resize_rule(t.shape[2], t.shape[3])
     if (h, w) != tuple(t.shape[2:]):
         t = F.interpolate(t, size=(h, w), mode="bilinear", align_corners=False)
@@ -65,17 +68,21 @@ def target_widths_host(boxes):
     return (np.maximum(2, gw // 32) * 32).tolist()
 
 
-def batched(net, converter, features, boxes, return_crops=False, gw_host=None):
+def batched(net, converter, features, boxes, return_crops=False, gw_host=None, batch_index=None):
     """All words of an image at once.  `boxes`: (N, >= 8) tensor on the device (or array).
     `gw_host`: the boxes' pooled widths when the caller already has them on the host (`infer_image`:
     the boxes come out of the host-side merge: `target_widths_host`) -- then nothing is
-    read back before the head."""
+    read back before the head.
+    `batch_index` (N,): the image each box belongs to when `features` hold SEVERAL images (`infer_batch`) -- the op's
+    own first ROI column (`tools/ocr_utils.py:151` writes 0 there: one image per call); still ONE RoIRotate launch."""
     focr = features[1]
     quads = torch.as_tensor(boxes, dtype=torch.float32, device=focr.device)[:, :8].contiguous()
     n = quads.shape[0]
     if n == 0:
         return ([], [], []) if return_crops else []
-    rois, gw = rois_from_quads(quads, None, False, TARGET_H)
+    if batch_index is not None:
+        batch_index = torch.as_tensor(batch_index, dtype=torch.float32).to(focr.device).contiguous()
+    rois, gw = rois_from_quads(quads, batch_index, False, TARGET_H)
     if gw_host is None:
         gw_host = gw.cpu()                              # the one read-back before the head
     else:
@@ -135,3 +142,46 @@ def infer_image(net, converter, im, detector=None, segm_thresh=0.5, return_debug
     keep = [i for i, t in enumerate(texts) if len(t) > 0]
     res = (boxes[keep], [texts[i] for i in keep])
     return res + ((boxes, out, feats),) if return_debug else res
+
+
+def infer_batch(net, converter, ims, detector=None, segm_thresh=0.5, return_debug=False):
+    """SEVERAL images of one size through the chain of `test.py:75-116` at once (round 6; the reference's loop takes one
+    image per pass, `test.py:62-75` -- its test set, ICDAR 2015, is 1280 x 720 throughout): ONE pass through the network
+    for the batch, `get_boxes` per image (every image's device decode is enqueued before the first read-back: one wait
+    for the batch), ONE RoIRotate launch for the words of ALL images (the op's batch index, `kernel.cu:46`), the
+    recognition head once per pooled-width bucket across the images, one read-back of the decoded labels.
+    -> a list of `infer_image`'s (boxes (n, 9) numpy, texts) per image, in order.  A word's crop is bit-identical to the
+    one the per-image chain cuts out of the same feature map (`tests/test_e2e_gpu.py`).
+
+    `ims`: a list of (H0, W0, 3) uint8 arrays that `resize_rule` maps to ONE size, or an (N, 3, H, W) tensor that is
+    already preprocessed.  `detector`: as in `infer_image`, for the whole batch: `im_data -> (score (N, h, w),
+    rbox (N, 4, h, w), angle (N, 2, h, w))`."""
+    from rroi_align.nms import get_boxes_batch
+    device = next(net.parameters()).device
+    if isinstance(ims, torch.Tensor):
+        im_data = ims
+    else:
+        sizes = {resize_rule(im.shape[0], im.shape[1]) for im in ims}
+        if len(sizes) != 1:
+            raise ValueError("infer_batch: the images must resize to one size, got %s (group them by size)" % sorted(sizes))
+        im_data = torch.cat([preprocess(im, device) for im in ims], 0)
+    nimg = im_data.shape[0]
+    score, rbox, angle, feats = net(im_data)
+    if detector is not None:
+        s, r, a = detector(im_data)
+    else:
+        s, r, a = score[0][:, 0], rbox[0], angle[0]
+    per_image = get_boxes_batch(s, r, a, segm_thresh)
+    counts = [len(b) for b in per_image]
+    boxes = np.concatenate(per_image, 0) if nimg else np.zeros((0, 9), np.float32)
+    bidx = np.repeat(np.arange(nimg, dtype=np.float32), counts)
+    out = batched(net, converter, feats, boxes, return_crops=return_debug, gw_host=target_widths_host(boxes) if len(boxes) else [],
+                  batch_index=bidx)
+    texts = out[0] if return_debug else out
+    res, at = [], 0
+    for b in range(nimg):
+        t = texts[at:at + counts[b]]
+        keep = [i for i, x in enumerate(t) if len(x) > 0]
+        res.append((per_image[b][keep], [t[i] for i in keep]))
+        at += counts[b]
+    return (res, (per_image, out, feats)) if return_debug else res

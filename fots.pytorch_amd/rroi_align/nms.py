@@ -69,3 +69,41 @@ def get_boxes(iou_map, rbox, angle_pred, segm_thresh=0.5):
     n = int(cnt.item())                      # the one synchronisation: how many pixels passed
     host = rec[:n].cpu().numpy()
     return merge(host, w, h, 0.4, 0.2)
+
+
+_merge_pool = None
+
+
+def _merge_workers():
+    """A few host threads for the merges of a batch (`rroi_nms_merge_host` keeps no state between calls and ctypes
+    releases the GIL around it); created on first use, never more than four."""
+    global _merge_pool
+    if _merge_pool is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            cpus = len(os.sched_getaffinity(0))
+        except AttributeError:  # pragma: no cover - non-Linux
+            cpus = os.cpu_count() or 1
+        _merge_pool = ThreadPoolExecutor(max_workers=max(1, min(4, cpus)), thread_name_prefix="rroi-nms-merge")
+    return _merge_pool
+
+
+def get_boxes_batch(iou_map, rbox, angle_pred, segm_thresh=0.5):
+    """`get_boxes` for the maps of SEVERAL images -- iou_map (N, h, w), rbox (N, 4, h, w), angle_pred (N, 2, h, w) on the
+    GPU -- with TWO host synchronisations for the batch instead of two per image: every image's decode launch is
+    enqueued first, the N counts come back together, then the passing pixels' records of all images in one copy; the
+    host merges (sequential code per image, as in the reference) run on a few threads side by side.
+    -> a list of N (n_i, 9) numpy fp32 arrays, each equal to `get_boxes` of that image's maps."""
+    n_img = iou_map.shape[0]
+    h, w = iou_map.shape[-2:]
+    pending = [decode(iou_map[i], rbox[i], angle_pred[i], segm_thresh) for i in range(n_img)]
+    if not pending:
+        return []
+    counts = torch.cat([c for _, c in pending]).cpu().tolist()      # synchronisation 1: how many pixels passed, per image
+    host = torch.cat([rec[:n] for (rec, _), n in zip(pending, counts)]).cpu().numpy()   # 2: their records
+    ends = np.cumsum(counts)
+    parts = [host[e - n:e] for e, n in zip(ends, counts)]
+    if n_img == 1:
+        return [merge(parts[0], w, h, 0.4, 0.2)]
+    return list(_merge_workers().map(lambda part: merge(part, w, h, 0.4, 0.2), parts))

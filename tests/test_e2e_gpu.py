@@ -168,3 +168,53 @@ def test_inference_chain_synchronises_once_before_the_head(setup):
     all_boxes = infer_image(net, conv, im_data, detector=hook, return_debug=True)[2][0]
     nbuckets = len(set(target_widths_host(all_boxes)))
     assert 2 <= len(syncs) <= 2 + 3 * nbuckets, (syncs, nbuckets)
+
+
+def test_image_batch_chain_equals_the_per_image_chain(setup):
+    """Round 6: `infer_batch` -- several images through ONE pass of the network, `get_boxes` per image behind one
+    synchronisation, ONE RoIRotate launch for the words of all images (the op's batch index, kernel.cu:46), the head per
+    pooled-width bucket across the images -- against the per-image pieces on the SAME feature maps: each image's boxes
+    equal `get_boxes` of its maps, each word's crop is bit-identical to the one `batched` cuts from that image alone,
+    the texts agree wherever the head's arg-max is not a numerical tie."""
+    from e2e_inputs import synthetic_detector_maps
+    from fots_e2e.pipeline import batched, infer_batch, infer_image
+    from rroi_align.nms import get_boxes
+    net, conv, dev = setup
+    size, nimg = (256, 384), 3
+    torch.manual_seed(6)
+    im_data = torch.rand(nimg, 3, *size, device=dev) * 2 - 1
+    maps = [tuple(torch.from_numpy(a).to(dev) for a in synthetic_detector_maps(size[0], size[1], 5 + 3 * i, seed=11 + i))
+            for i in range(nimg)]
+    hook = lambda _x: tuple(torch.stack([m[j] for m in maps]) for j in range(3))   # noqa: E731
+    with torch.no_grad():
+        res, (per_image, (all_t, c_bat, l_bat), feats) = infer_batch(net, conv, im_data, detector=hook, return_debug=True)
+        assert len(res) == len(per_image) == nimg and feats[1].shape[0] == nimg
+        at, exact = 0, True
+        for b in range(nimg):
+            boxes_b = get_boxes(*maps[b], 0.5)
+            assert len(boxes_b) >= 2 and np.array_equal(boxes_b, per_image[b])
+            t1, c1, l1 = batched(net, conv, [f[b:b + 1].contiguous() for f in feats], boxes_b, return_crops=True)
+            for i in range(len(boxes_b)):
+                assert c1[i].shape == c_bat[at + i].shape and torch.equal(c1[i], c_bat[at + i]), "image %d crop %d" % (b, i)
+                if not torch.equal(l1[i], l_bat[at + i]):
+                    exact = False
+                    top2 = net.forward_ocr(c1[i]).topk(2, dim=1).values[0]
+                    assert float((top2[0] - top2[1])[l1[i] != l_bat[at + i]].abs().max()) < 2e-3
+                else:
+                    assert t1[i] == all_t[at + i]
+            if exact:
+                keep = [i for i, t in enumerate(t1) if len(t) > 0]
+                assert res[b][1] == [t1[i] for i in keep] and np.array_equal(res[b][0], boxes_b[keep])
+            at += len(boxes_b)
+        assert at == len(all_t)
+        # a batch of one is the per-image chain; an image without a word yields an empty entry, not a shorter list
+        one = infer_batch(net, conv, im_data[:1], detector=lambda _x: tuple(m[:1] for m in hook(_x)))
+        kept, texts = infer_image(net, conv, im_data[:1], detector=lambda _x: maps[0])
+        assert len(one) == 1 and len(one[0][0]) == len(one[0][1]) and len(kept) == len(texts)
+        if one[0][1] == texts:   # (two passes through MIOpen need not agree in the last bit: only then are the kept sets comparable)
+            assert np.array_equal(one[0][0], kept)
+        blank = tuple(torch.zeros_like(t) for t in hook(None))
+        empty = infer_batch(net, conv, im_data, detector=lambda _x: blank)
+        assert [len(t) for _, t in empty] == [0] * nimg and all(b.shape == (0, 9) for b, _ in empty)
+    with pytest.raises(ValueError):
+        infer_batch(net, conv, [np.zeros((720, 1280, 3), np.uint8), np.zeros((512, 512, 3), np.uint8)])

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Round 6: would a MULTI-IMAGE batch through the backbone pay?  ms per image of FOTSNet (fp32, NCHW, random weights) at
+1280 x 704 for B = 1, 2, 4, 8 images per forward."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "fots.pytorch_amd")]
+from fots_e2e.alphabet import ALPHABET
+from fots_e2e.hostcpus import cap_torch_threads
+from fots_e2e.model import FOTSNet
+from fots_e2e.weights import deterministic_init
+cap_torch_threads()
+dev = torch.device("cuda", 0)
+net = deterministic_init(FOTSNet(len(ALPHABET) + 1)).eval().to(dev)
+with torch.no_grad():
+    for B in (1, 2, 4, 8, 1):
+        x = torch.randn(B, 3, 704, 1280, device=dev)
+        for _ in range(3): net(x)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(8):
+            t0 = time.perf_counter(); net(x); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        print(f"B={B}: {np.median(ts) * 1e3:7.2f} ms per forward, {np.median(ts) * 1e3 / B:6.2f} ms per image", flush=True)
