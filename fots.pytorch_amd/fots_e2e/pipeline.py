@@ -106,9 +106,9 @@ def batched(net, converter, features, boxes, return_crops=False, gw_host=None, b
         decoded, dlen, lab = ctc_greedy_decode(logp, None, return_labels=True)
         pending.append((idx, decoded, dlen, x, lab))
     for idx, decoded, dlen, x, lab in pending:
-        decoded, dlen = decoded.cpu(), dlen.cpu()       # the first of these waits for the whole image
+        words = converter.to_texts(decoded, dlen)       # the first of these waits for the whole image
         for j, i in enumerate(idx):
-            texts[i] = converter.to_text(decoded[j, :int(dlen[j])])
+            texts[i] = words[j]
             if return_crops:
                 crops[i], labels[i] = x[j:j + 1], lab[j].to(torch.int64)
     return (texts, crops, labels) if return_crops else texts

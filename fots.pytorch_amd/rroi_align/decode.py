@@ -31,12 +31,21 @@ class CTCLabelConverter(object):
     def decode_logits(self, logits, lengths=None):
         """logits (N, nclass, T) on the GPU -> list of N strings (one kernel, one copy)."""
         decoded, dlen = ctc_greedy_decode(logits, lengths)
-        decoded, dlen = decoded.cpu(), dlen.cpu()
-        return [self.to_text(decoded[i, :int(dlen[i])]) for i in range(decoded.size(0))]
+        return self.to_texts(decoded, dlen)
+
+    def to_texts(self, decoded, decoded_len):
+        """(N, T) collapsed labels + (N,) lengths (device or host tensors) -> N strings.  ONE copy each and plain lists from
+        there on: indexing and iterating a tensor per word and per label costs 30 us a word (round 6: 0.7 of the 1.8 ms the
+        recognition of an image's 24 words took)."""
+        rows, lens = decoded.cpu().tolist(), decoded_len.cpu().tolist()
+        return [self.to_text(row[:n]) for row, n in zip(rows, lens)]
 
     def to_text(self, kept_labels):
         """Already-collapsed labels -> string (the inner expression of src/utils.py:96)."""
-        return ''.join(self.alphabet[int(t) - 1] for t in kept_labels)
+        if isinstance(kept_labels, torch.Tensor):
+            kept_labels = kept_labels.tolist()
+        alphabet = self.alphabet
+        return ''.join([alphabet[int(t) - 1] for t in kept_labels])
 
     def decode(self, t, length, raw=False):
         """Host-side decode of ONE label sequence, `strLabelConverter.decode` semantics
