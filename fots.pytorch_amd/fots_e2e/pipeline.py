@@ -158,6 +158,8 @@ def infer_batch(net, converter, ims, detector=None, segm_thresh=0.5, return_debu
     rbox (N, 4, h, w), angle (N, 2, h, w))`."""
     from rroi_align.nms import get_boxes_batch
     device = next(net.parameters()).device
+    if len(ims) == 0:
+        return ([], ([], ([], [], []), None)) if return_debug else []
     if isinstance(ims, torch.Tensor):
         im_data = ims
     else:
