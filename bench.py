@@ -27,7 +27,8 @@ Prints ONE JSON line on rank 0.
                    no runnable CPU path) timed on this host's cores -- a reported baseline, not the
                    thing measured.
   extra            `sensitivity`: the call with every bin active and with axis-aligned ROIs,
-                   next to a control run of the default draw in the same loop;
+                   next to a control run of the default draw in the same loop; `two_calls_in_flight`: the same call
+                   with consecutive calls alternating between two streams (round 6; not `value`);
                    N > 1: the step followed by the RCCL all_gather of the crops into one
                    preallocated (512*N, 256, 8, 64) buffer (`with_gather_ms`) and the 25 MiB all_reduce
                    of the feature gradient (`with_allreduce_grad_ms`), reported beside the kernel-only
@@ -48,7 +49,7 @@ import time
 import numpy as np
 import torch
 
-from bench_legs import beyond_cache, mixed_layout, train_regime, train_step
+from bench_legs import beyond_cache, mixed_layout, train_regime, train_step, two_calls_in_flight
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "fots.pytorch_amd"))
@@ -499,6 +500,15 @@ def run(args):
                             "back-to-back run; this is what a call costs in the middle of other work"}
         del other_a, other_m
 
+    # two calls in flight on two streams (round 6): what the write path does when it is never left idle
+    inflight = None
+    if world == 1 and os.environ.get("RROI_BENCH_SENSITIVITY", "1") == "1":
+        try:
+            inflight = two_calls_in_flight(ext, dev, c, feats, rois, R * c["C"] * c["PH"] * c["PW"] * 4 + R * 24
+                                           + TOUCHED_PIXELS_RANK0 * c["C"] * 4)
+        except Exception as e:
+            inflight = {"error": repr(e)[:300]}
+
     train = None
     if world == 1 and os.environ.get("RROI_BENCH_TRAIN", "1") == "1":
         try:
@@ -683,6 +693,7 @@ def run(args):
         "extra": {
             "sensitivity": sensitivity,
             "isolated_call_ms": isolated,
+            "two_calls_in_flight": inflight,
             "ranks": ranks_info,
             "with_gather_ms": None if with_gather_ms is None else round(with_gather_ms, 4),
             "with_allreduce_grad_ms": None if with_allreduce_ms is None else round(with_allreduce_ms, 4),

@@ -1,5 +1,5 @@
 """bench_legs.py -- the side legs of bench.py's line (`extra.train_regime`, `extra.beyond_cache`, `extra.mixed_layout`,
-`extra.train_step`): benchmark code, not part of the product package; none of it enters `value`.
+`extra.train_step`, `extra.two_calls_in_flight`): benchmark code, not part of the product package; none of it enters `value`.
 
 Round 6 moved the first two out of bench.py and added the other two: the hand-off layouts the FOTS pipeline can actually
 reach (VERDICT r05 item 1 -- the reference's backbone emits NCHW features, tools/models.py:387-457, and its head consumes
@@ -253,3 +253,48 @@ def train_step(ext, dev, event_loop):
                     "step -- three times the op's whole cost -- so the callers' modules keep the reference's contract for NCHW features "
                     "(DESIGN.md 5.5)")
     return rows
+
+
+def two_calls_in_flight(ext, dev, c, feats, rois, algorithmic_bytes, calls=600, warm=300):
+    """Round 6: configs[1] with TWO calls in flight -- consecutive calls alternate between two HIP streams, each with its own
+    crops and its own workspace (every call does all of its work and writes all of its output; the two crops tensors are
+    compared bit for bit), so that one call's prologue and start-up run beside the other's store stream.  Wall clock per call
+    over `calls` calls after `warm`, synchronised on both sides; the one-stream figure by the same loop beside it.  Not
+    `value`: the headline stays the SEQUENTIAL call, which is what a caller with one feature map at a time gets."""
+    import time
+    R = rois.shape[0]
+    nb = ext._lib.rroi_align_forward_workspace_bytes(1, c["C"], c["H"], c["W"], R, ext.LAYOUT_NCHW)
+
+    def run(nstreams):
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+        outs = [torch.empty((R, c["C"], c["PH"], c["PW"]), dtype=torch.float32, device=dev) for _ in range(nstreams)]
+        wss = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(nstreams)]
+        torch.cuda.synchronize()
+
+        def call(i):
+            s = i % nstreams
+            st = ext._lib.rroi_align_forward_stages_hip(feats.data_ptr(), ext.LAYOUT_NCHW, c["scale"], 1, R, c["H"], c["W"], c["C"],
+                                                        c["PH"], c["PW"], rois.data_ptr(), outs[s].data_ptr(), wss[s].data_ptr(), nb,
+                                                        ext.PATH_TILED, ext.STAGE_ALL, streams[s].cuda_stream)
+            if st != 1:
+                raise RuntimeError(f"two_calls_in_flight -> {st}")
+        for i in range(warm):
+            call(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(calls):
+            call(i)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / calls * 1e3
+        return ms, all(torch.equal(outs[0], o) for o in outs[1:])
+    one_ms, _ = run(1)
+    two_ms, same = run(2)
+    return {"ms_per_call": round(two_ms, 5), "ROIs/s": round(R / (two_ms * 1e-3), 1),
+            "whole_call_frac": round(algorithmic_bytes / (two_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "one_stream_ms_per_call": round(one_ms, 5),
+            "one_stream_whole_call_frac": round(algorithmic_bytes / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "crops_identical": bool(same),
+            "what": "configs[1], consecutive calls alternating between two HIP streams (own crops and workspace each): wall clock per "
+                    "call over %d calls after %d, synchronised on both sides; one_stream_* = the same loop on one stream.  The "
+                    "sequential call leaves the write path idle while a prologue and a gather's first taps run; a second call in "
+                    "flight fills that.  Not `value`" % (calls, warm)}
