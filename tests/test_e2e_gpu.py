@@ -216,5 +216,6 @@ def test_image_batch_chain_equals_the_per_image_chain(setup):
         blank = tuple(torch.zeros_like(t) for t in hook(None))
         empty = infer_batch(net, conv, im_data, detector=lambda _x: blank)
         assert [len(t) for _, t in empty] == [0] * nimg and all(b.shape == (0, 9) for b, _ in empty)
+    assert infer_batch(net, conv, []) == []
     with pytest.raises(ValueError):
         infer_batch(net, conv, [np.zeros((720, 1280, 3), np.uint8), np.zeros((512, 512, 3), np.uint8)])
