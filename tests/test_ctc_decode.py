@@ -44,6 +44,21 @@ def test_host_converter_mirrors_reference(gold):
         conv.decode(torch.zeros(5, dtype=torch.int32), torch.IntTensor([4]))
 
 
+def test_host_converter_batch_of_collapsed_labels(gold):
+    """`to_texts` (round 6: one copy, plain lists) against the reference's texts and against `to_text` word by word, for
+    tensors, arrays and lists of labels."""
+    from rroi_align.decode import CTCLabelConverter
+    conv = CTCLabelConverter(str(gold["alphabet"]))
+    dec, dlen = CO.collapse(gold["labels"])
+    want = [str(t) for t in gold["texts"]]
+    assert conv.to_texts(torch.from_numpy(dec.astype(np.int32)), torch.from_numpy(dlen.astype(np.int32))) == want
+    for n in range(len(want)):
+        row = dec[n, :dlen[n]]
+        assert conv.to_text(torch.from_numpy(row.astype(np.int32))) == conv.to_text(row) == conv.to_text(row.tolist()) == want[n]
+    assert conv.to_texts(torch.zeros((0, 7), dtype=torch.int32), torch.zeros((0,), dtype=torch.int32)) == []
+    assert conv.to_text([]) == ""
+
+
 def test_oracle_rules():
     x = np.zeros((1, 4, 6), np.float32)
     x[0, 2, 0] = 1; x[0, 2, 1] = 1          # repeated label collapses
