@@ -61,6 +61,17 @@ int main()
       printf("hipGetDevice + hipGetLastError: %.3f us per pair\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 1e5); }
     { auto t0 = std::chrono::steady_clock::now(); int ok = 0; for (int i = 0; i < 100000; ++i) ok += fwd(feats, RROI_LAYOUT_NCHW, 0.25f, B, 0, H, W, C, PH, PW, feats, feats, nullptr, 0, RROI_PATH_AUTO, st);
       printf("forward with num_rois = 0 (validation only): %.3f us per call (%d)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 1e5, ok); }
+    {   // fork / join between two streams around one empty kernel each: what an in-call second stream would cost per call
+        hipStream_t s2; (void)hipStreamCreate(&s2);
+        hipEvent_t f, j; (void)hipEventCreateWithFlags(&f, hipEventDisableTiming); (void)hipEventCreateWithFlags(&j, hipEventDisableTiming);
+        loop([&] { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, st); hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, st); },
+             500, 5000, "two empty kernels on one stream");
+        loop([&] { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, st);
+                   (void)hipEventRecord(f, st); (void)hipStreamWaitEvent(s2, f, 0);
+                   hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s2);
+                   (void)hipEventRecord(j, s2); (void)hipStreamWaitEvent(st, j, 0); },
+             500, 5000, "the same with the second one forked to / joined from another stream");
+    }
     for (int R : {1, 8, 16, 32, 64}) {
         std::uniform_real_distribution<float> u(0.f, 1.f);
         std::vector<float> hr((size_t)R * 6);
