@@ -864,6 +864,32 @@ def test_other_stream_and_reentrancy(ext, oracle):
         assert eq(o.cpu().numpy(), want)
 
 
+def test_two_calls_in_flight_on_two_streams(ext, oracle):
+    """Round 6 (`extra.two_calls_in_flight`): consecutive calls alternate between two streams and run side by side on the
+    device -- different ROIs per stream, so that a workspace (chunk-major copy, affine table, ROI order) shared between
+    two calls in flight would show; forward through the two-launch path and the backward's list path, each against the
+    oracle."""
+    f, r0 = Wk.bench_inputs(R=96, C=64, H=64, W=96, img=384, seed=31)
+    _, r1 = Wk.bench_inputs(R=96, C=64, H=64, W=96, img=384, seed=32)
+    want = [oracle.forward_c(f, r, 8, 64, 0.25, threads=8) for r in (r0, r1)]
+    g = np.random.default_rng(3).standard_normal(want[0].shape).astype(np.float32)
+    gwant = [oracle.backward_c(g, r, f.shape, 0.25, threads=8) for r in (r0, r1)]
+    F, G, Rr = dev(f), dev(g), [dev(r0), dev(r1)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs, grads = [], []
+    for i in range(8):
+        with torch.cuda.stream(streams[i % 2]):
+            outs.append(ext.forward(F, Rr[i % 2], 8, 64, 0.25, path=ext.PATH_TILED))
+            grads.append(ext.backward(G, Rr[i % 2], f.shape, 0.25, path=ext.PATH_TILED))
+    for s in streams:
+        s.synchronize()
+    for i, (o, gi) in enumerate(zip(outs, grads)):
+        assert eq(o.cpu().numpy(), want[i % 2]), "forward of call %d" % i
+        scale = max(1.0, float(np.abs(gwant[i % 2]).max()))
+        assert float(np.abs(gi.cpu().numpy() - gwant[i % 2]).max()) <= 1e-4 * scale, "backward of call %d" % i
+
+
 def test_invalid_batch_index_yields_zeros(ext):
     f, r = Wk.bench_inputs(R=4, C=8, seed=18)
     r[1, 0] = 5
