@@ -26,7 +26,7 @@ for _p in (ROOT, os.path.join(ROOT, "fots.pytorch_amd")):
 from fots_e2e.alphabet import ALPHABET  # noqa: E402
 from fots_e2e.hostcpus import cap_torch_threads  # noqa: E402
 from fots_e2e.model import FOTSNet  # noqa: E402
-from fots_e2e.pipeline import batched, infer_batch, infer_image, preprocess, resize_rule  # noqa: E402
+from fots_e2e.pipeline import batched, infer_batch, infer_image, infer_stream, preprocess, resize_rule  # noqa: E402
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
 from e2e_inputs import synthetic_boxes, synthetic_detector_maps  # noqa: E402  (input generators, not product)
 from fots_e2e.weights import deterministic_init  # noqa: E402
@@ -159,6 +159,29 @@ def measure(device, reps=5, channels_last=False):
                               "what": "infer_batch: %d images per pass of the network (uploads and preprocessing included), "
                                       "get_boxes per image behind one synchronisation, ONE RoIRotate launch for the words of all "
                                       "images (the op's batch index), the head per pooled-width bucket across the images" % IMAGES_PER_BATCH}
+        # ... and with two batches in flight (`infer_stream`): batch k's read-backs, host merges, recognition and strings on a
+        # side stream beside the network pass of batch k + 1 -- wall clock over the whole sequence
+        n_seq = max(2, 2 * min(reps, 3)) * len(groups)
+        seq_groups = [groups[i % len(groups)] for i in range(n_seq)]
+        seq_maps = [tuple(torch.stack([maps[i][j] for i in g]) for j in range(3)) for g in seq_groups]
+
+        def run_stream():
+            nb = 0
+            for r in infer_stream(net, conv, ([ims[i] for i in g] for g in seq_groups), detector=lambda k, _x: seq_maps[k]):
+                nb += sum(len(b) for b, _t in r)
+            return nb
+        run_stream()                                           # warm-up (the side stream's MIOpen handle and workspaces)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        nbox = run_stream()
+        torch.cuda.synchronize(device)
+        wall = time.perf_counter() - t0
+        out["image_stream"] = {"images_per_batch": IMAGES_PER_BATCH, "batches": n_seq,
+                               "chain_images_per_s": round(IMAGES_PER_BATCH * n_seq / wall, 2),
+                               "chain_boxes_per_image": round(nbox / (IMAGES_PER_BATCH * n_seq), 1),
+                               "what": "infer_stream: the image_batch chain with two batches in flight -- batch k's second half "
+                                       "(read-backs, host merges, RoIRotate, head, strings) on a side stream beside the network "
+                                       "pass of batch k + 1; wall clock over %d batches" % n_seq}
     out["chain"] = ("chain_*: preprocess + net + rroi_align.nms.get_boxes on the device maps (synthetic trained-detector "
                     "maps injected for the three head outputs: random weights pass no box) + recognition of the boxes "
                     "get_boxes returned; host synchronisations per image on the batched path: the read-back of the "

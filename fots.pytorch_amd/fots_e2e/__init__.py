@@ -6,7 +6,8 @@ RoIRotate launch with R = 1, the recognition head (`models.py:334-379`), arg max
 decode (`tools/ocr_utils.py:131-199`).  This package is that pipeline on PyTorch-ROCm around the HIP op in
 its MI355X shape (`pipeline.batched`, `pipeline.infer_image`) -- ROIs built on the device, ONE RoIRotate
 launch per image, the head once per pooled-width bucket, one batched greedy-CTC launch; `pipeline.infer_batch` (round 6)
-takes SEVERAL images of one size through one pass of the network and one RoIRotate launch (the op's batch index).  The reference's
+takes SEVERAL images of one size through one pass of the network and one RoIRotate launch (the op's batch index), and
+`pipeline.infer_stream` keeps two such batches in flight.  The reference's
 per-word structure is kept with the checkers (`oracle/e2e_loop_oracle.py`: the tests' comparison, the
 benchmark's baseline leg), not here.
 

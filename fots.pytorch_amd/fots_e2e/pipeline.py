@@ -144,22 +144,11 @@ def infer_image(net, converter, im, detector=None, segm_thresh=0.5, return_debug
     return res + ((boxes, out, feats),) if return_debug else res
 
 
-def infer_batch(net, converter, ims, detector=None, segm_thresh=0.5, return_debug=False):
-    """SEVERAL images of one size through the chain of `test.py:75-116` at once (round 6; the reference's loop takes one
-    image per pass, `test.py:62-75` -- its test set, ICDAR 2015, is 1280 x 720 throughout): ONE pass through the network
-    for the batch, `get_boxes` per image (every image's device decode is enqueued before the first read-back: one wait
-    for the batch), ONE RoIRotate launch for the words of ALL images (the op's batch index, `kernel.cu:46`), the
-    recognition head once per pooled-width bucket across the images, one read-back of the decoded labels.
-    -> a list of `infer_image`'s (boxes (n, 9) numpy, texts) per image, in order.  A word's crop is bit-identical to the
-    one the per-image chain cuts out of the same feature map (`tests/test_e2e_gpu.py`).
-
-    `ims`: a list of (H0, W0, 3) uint8 arrays that `resize_rule` maps to ONE size, or an (N, 3, H, W) tensor that is
-    already preprocessed.  `detector`: as in `infer_image`, for the whole batch: `im_data -> (score (N, h, w),
-    rbox (N, 4, h, w), angle (N, 2, h, w))`."""
-    from rroi_align.nms import get_boxes_batch
+def _batch_front(net, ims, detector, segm_thresh):
+    """The first half of `infer_batch`, ENQUEUED on the current stream and nothing read back: preprocessing, one pass of the
+    network, one decode launch per image."""
+    from rroi_align.nms import decode_batch
     device = next(net.parameters()).device
-    if len(ims) == 0:
-        return ([], ([], ([], [], []), None)) if return_debug else []
     if isinstance(ims, torch.Tensor):
         im_data = ims
     else:
@@ -167,13 +156,20 @@ def infer_batch(net, converter, ims, detector=None, segm_thresh=0.5, return_debu
         if len(sizes) != 1:
             raise ValueError("infer_batch: the images must resize to one size, got %s (group them by size)" % sorted(sizes))
         im_data = torch.cat([preprocess(im, device) for im in ims], 0)
-    nimg = im_data.shape[0]
     score, rbox, angle, feats = net(im_data)
     if detector is not None:
         s, r, a = detector(im_data)
     else:
         s, r, a = score[0][:, 0], rbox[0], angle[0]
-    per_image = get_boxes_batch(s, r, a, segm_thresh)
+    return im_data.shape[0], feats, decode_batch(s, r, a, segm_thresh)
+
+
+def _batch_back(net, converter, front, return_debug=False):
+    """The second half, on the current stream: the boxes of every image (`merge_decoded`: two synchronisations, host merges),
+    ONE RoIRotate launch for all their words, the head per pooled-width bucket, the strings."""
+    from rroi_align.nms import merge_decoded
+    nimg, feats, decoded = front
+    per_image = merge_decoded(decoded)
     counts = [len(b) for b in per_image]
     boxes = np.concatenate(per_image, 0) if nimg else np.zeros((0, 9), np.float32)
     bidx = np.repeat(np.arange(nimg, dtype=np.float32), counts)
@@ -187,3 +183,53 @@ def infer_batch(net, converter, ims, detector=None, segm_thresh=0.5, return_debu
         res.append((per_image[b][keep], [t[i] for i in keep]))
         at += counts[b]
     return (res, (per_image, out, feats)) if return_debug else res
+
+
+def infer_batch(net, converter, ims, detector=None, segm_thresh=0.5, return_debug=False):
+    """SEVERAL images of one size through the chain of `test.py:75-116` at once (round 6; the reference's loop takes one
+    image per pass, `test.py:62-75` -- its test set, ICDAR 2015, is 1280 x 720 throughout): ONE pass through the network
+    for the batch, `get_boxes` per image (every image's device decode is enqueued before the first read-back: one wait
+    for the batch), ONE RoIRotate launch for the words of ALL images (the op's batch index, `kernel.cu:46`), the
+    recognition head once per pooled-width bucket across the images, one read-back of the decoded labels.
+    -> a list of `infer_image`'s (boxes (n, 9) numpy, texts) per image, in order.  A word's crop is bit-identical to the
+    one the per-image chain cuts out of the same feature map (`tests/test_e2e_gpu.py`).
+
+    `ims`: a list of (H0, W0, 3) uint8 arrays that `resize_rule` maps to ONE size, or an (N, 3, H, W) tensor that is
+    already preprocessed.  `detector`: as in `infer_image`, for the whole batch: `im_data -> (score (N, h, w),
+    rbox (N, 4, h, w), angle (N, 2, h, w))`."""
+    if len(ims) == 0:
+        return ([], ([], ([], [], []), None)) if return_debug else []
+    return _batch_back(net, converter, _batch_front(net, ims, detector, segm_thresh), return_debug)
+
+
+def infer_stream(net, converter, batches, detector=None, segm_thresh=0.5):
+    """`infer_batch` over a SEQUENCE of batches with two batches in flight (a generator: one list of (boxes, texts) per
+    batch, in order): the network pass of batch k + 1 is enqueued on the caller's stream BEFORE batch k's boxes are read
+    back, and batch k's second half -- read-backs, host merges, RoIRotate, head, strings -- runs on a second stream
+    beside it.  The device never waits for the host's merges and string building, the host never waits for a network
+    pass it does not need yet; results are those of `infer_batch` (same kernels on the same data).  `detector`: a callable
+    `(k, im_data) -> maps` (the batch's index first), or None."""
+    device = next(net.parameters()).device
+    side = torch.cuda.Stream(device=device)
+
+    def back(front, ready):
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            res = _batch_back(net, converter, front)      # its read-backs synchronise `side` only
+        return res
+    prev = None
+    for k, ims in enumerate(batches):
+        if len(ims) == 0:
+            if prev is not None:
+                yield back(*prev)
+                prev = None
+            yield []
+            continue
+        front = _batch_front(net, ims, None if detector is None else (lambda x, k=k: detector(k, x)), segm_thresh)
+        ready = torch.cuda.Event()
+        ready.record()
+        if prev is not None:
+            yield back(*prev)
+        prev = (front, ready)
+    if prev is not None:
+        yield back(*prev)

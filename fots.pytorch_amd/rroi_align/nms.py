@@ -89,21 +89,31 @@ def _merge_workers():
     return _merge_pool
 
 
-def get_boxes_batch(iou_map, rbox, angle_pred, segm_thresh=0.5):
-    """`get_boxes` for the maps of SEVERAL images -- iou_map (N, h, w), rbox (N, 4, h, w), angle_pred (N, 2, h, w) on the
-    GPU -- with TWO host synchronisations for the batch instead of two per image: every image's decode launch is
-    enqueued first, the N counts come back together, then the passing pixels' records of all images in one copy; the
-    host merges (sequential code per image, as in the reference) run on a few threads side by side.
-    -> a list of N (n_i, 9) numpy fp32 arrays, each equal to `get_boxes` of that image's maps."""
+def decode_batch(iou_map, rbox, angle_pred, segm_thresh=0.5):
+    """The device half of `get_boxes_batch`: one decode launch per image, nothing read back -> what `merge_decoded` takes."""
     n_img = iou_map.shape[0]
-    h, w = iou_map.shape[-2:]
-    pending = [decode(iou_map[i], rbox[i], angle_pred[i], segm_thresh) for i in range(n_img)]
+    return [decode(iou_map[i], rbox[i], angle_pred[i], segm_thresh) for i in range(n_img)], tuple(iou_map.shape[-2:])
+
+
+def merge_decoded(decoded):
+    """The host half: the N counts come back together, then the passing pixels' records of all images in one copy (two
+    synchronisations of the CURRENT stream for the batch); the merges -- sequential code per image, as in the reference --
+    run on a few threads side by side.  -> a list of N (n_i, 9) numpy fp32 arrays."""
+    pending, (h, w) = decoded
     if not pending:
         return []
     counts = torch.cat([c for _, c in pending]).cpu().tolist()      # synchronisation 1: how many pixels passed, per image
     host = torch.cat([rec[:n] for (rec, _), n in zip(pending, counts)]).cpu().numpy()   # 2: their records
     ends = np.cumsum(counts)
     parts = [host[e - n:e] for e, n in zip(ends, counts)]
-    if n_img == 1:
+    if len(parts) == 1:
         return [merge(parts[0], w, h, 0.4, 0.2)]
     return list(_merge_workers().map(lambda part: merge(part, w, h, 0.4, 0.2), parts))
+
+
+def get_boxes_batch(iou_map, rbox, angle_pred, segm_thresh=0.5):
+    """`get_boxes` for the maps of SEVERAL images -- iou_map (N, h, w), rbox (N, 4, h, w), angle_pred (N, 2, h, w) on the
+    GPU -- with TWO host synchronisations for the batch instead of two per image: every image's decode launch is
+    enqueued first (`decode_batch`), then `merge_decoded`.
+    -> a list of N (n_i, 9) numpy fp32 arrays, each equal to `get_boxes` of that image's maps."""
+    return merge_decoded(decode_batch(iou_map, rbox, angle_pred, segm_thresh))

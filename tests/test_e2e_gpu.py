@@ -219,3 +219,35 @@ def test_image_batch_chain_equals_the_per_image_chain(setup):
     assert infer_batch(net, conv, []) == []
     with pytest.raises(ValueError):
         infer_batch(net, conv, [np.zeros((720, 1280, 3), np.uint8), np.zeros((512, 512, 3), np.uint8)])
+
+
+def test_image_stream_equals_the_batches_one_by_one(setup):
+    """Round 6: `infer_stream` -- two batches in flight, the second half of batch k on a side stream beside the network pass
+    of batch k + 1 -- yields, batch by batch and in order, what `infer_batch` yields for the same inputs: the same boxes per
+    image (they come from the injected detector maps), as many texts as boxes, and the same texts wherever the two passes
+    through the head agree (random weights put some arg-max decisions on numerical ties)."""
+    from e2e_inputs import synthetic_detector_maps
+    from fots_e2e.pipeline import infer_batch, infer_stream
+    from rroi_align.nms import get_boxes
+    net, conv, dev = setup
+    size, nimg, nbatch = (256, 384), 2, 4
+    torch.manual_seed(8)
+    batches = [torch.rand(nimg, 3, *size, device=dev) * 2 - 1 for _ in range(nbatch)]
+    maps = [[tuple(torch.from_numpy(a).to(dev) for a in synthetic_detector_maps(size[0], size[1], 4 + k + 2 * i, seed=40 + 7 * k + i))
+             for i in range(nimg)] for k in range(nbatch)]
+    stacked = [tuple(torch.stack([m[j] for m in maps[k]]) for j in range(3)) for k in range(nbatch)]
+    with torch.no_grad():
+        seq = list(infer_stream(net, conv, batches[:2] + [[]] + batches[2:], detector=lambda k, _x: stacked[k if k < 2 else k - 1]))
+        assert len(seq) == nbatch + 1 and seq[2] == []
+        seq = seq[:2] + seq[3:]
+        for k in range(nbatch):
+            one = infer_batch(net, conv, batches[k], detector=lambda _x, k=k: stacked[k])
+            assert len(seq[k]) == len(one) == nimg
+            for i in range(nimg):
+                all_boxes = get_boxes(*maps[k][i], 0.5)
+                (bs, ts), (bo, to) = seq[k][i], one[i]
+                assert len(bs) == len(ts) and len(bo) == len(to) and len(all_boxes) >= len(bs)
+                assert all(any(np.array_equal(b, a) for a in all_boxes) for b in bs)
+                if ts == to:
+                    assert np.array_equal(bs, bo)
+        assert list(infer_stream(net, conv, [])) == []
