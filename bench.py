@@ -661,6 +661,9 @@ def run(args):
         "roofline": {"bound": "hbm", "kernel": "rroi_fwd_split_kernel", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "whole_call_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     # the same bytes over the per-call wall time with TWO calls in flight on two streams (extra.two_calls_in_flight;
+                     # `value` and whole_call_frac stay the sequential call)
+                     "whole_call_frac_two_in_flight": None if not inflight or "whole_call_frac" not in inflight else inflight["whole_call_frac"],
                      "traffic": traffic,
                      "traffic_measured": traffic_measured,
                      "traffic_source": traffic_source,
